@@ -1,0 +1,152 @@
+/* C ABI of the MI355X-native differentiable Gaussian rasteriser + simple-knn.
+ *
+ * This is the drop-in boundary for the two native extensions MonoGS binds
+ * (paths relative to the reference tree /root/reference):
+ *
+ *   diff_gaussian_rasterization._C.rasterize_gaussians / rasterize_gaussians_backward
+ *       - constructed/called at gaussian_splatting/gaussian_renderer/__init__.py:61-77,151-168
+ *       - upstream binding: submodules/diff-gaussian-rasterization (git submodule,
+ *         .gitmodules:4-7, source absent from the tree)
+ *   simple_knn._C.distCUDA2
+ *       - called at gaussian_splatting/scene/gaussian_model.py:18,185-191
+ *       - upstream binding: submodules/simple-knn (.gitmodules:1-3, source absent)
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless named host_*; all floats are
+ *     fp32, ids/counters int32, sort keys uint64; tensors are dense row-major;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and no
+ *     entry point synchronises with the host;
+ *   - the library owns no device memory and keeps no state between calls: scratch
+ *     lives in caller-owned workspaces whose sizes come from mgs_raster_workspace_query;
+ *   - every function returns 0 on success or a negative mgs_status; nothing throws
+ *     across this boundary.  mgs_status_string() names a code.
+ */
+#ifndef MONOGS_RASTER_H
+#define MONOGS_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGS_ABI_VERSION 1
+
+typedef enum mgs_status {
+  MGS_OK = 0,
+  MGS_ERR_BAD_ARGUMENT = -1,   /* null pointer / non-positive size / bad degree */
+  MGS_ERR_LAUNCH = -2,         /* hipGetLastError() after a launch was not hipSuccess */
+  MGS_ERR_UNSUPPORTED = -3,
+} mgs_status;
+
+/* Problem shape shared by forward and backward. */
+typedef struct mgs_raster_shape {
+  int32_t num_gaussians;   /* N >= 1 (N == 0 is handled above the boundary,
+                              gaussian_renderer/__init__.py:43-44) */
+  int32_t width, height;
+  int32_t sh_degree;       /* active degree 0..3 */
+  int32_t sh_coeffs;       /* K: coefficient triples stored per Gaussian in `shs` [N,K,3] */
+  int32_t pair_capacity;   /* capacity (in (tile,Gaussian) pairs) of the `bins` workspace */
+  float tanfovx, tanfovy;
+  float scale_modifier;
+} mgs_raster_shape;
+
+/* Byte sizes of the caller-owned workspaces for a shape. */
+typedef struct mgs_workspace_sizes {
+  uint64_t geom_bytes;   /* per-Gaussian records, per-tile ranges, per-pixel blend state;
+                            written by forward, read by backward (save it on the autograd ctx) */
+  uint64_t bins_bytes;   /* pair_capacity sorted (key, payload) pairs; forward -> backward */
+  uint64_t bwd_bytes;    /* backward-only scratch (per-pair reduced gradients, scans) */
+  uint64_t sketch_bytes; /* extra backward scratch, only when sketch_mode != 0 */
+  /* byte offsets inside `geom` of arrays tests may inspect */
+  uint64_t off_records;      /* N x 48 B  mgs SplatRec                       */
+  uint64_t off_pair_count;   /* N x int32 pairs emitted per Gaussian         */
+  uint64_t off_tile_offset;  /* (T+1) x int32 exclusive scan of tile counts  */
+  uint64_t off_final_T;      /* W*H x float                                  */
+  uint64_t off_n_contrib;    /* W*H x int32                                  */
+  uint64_t off_counters;     /* 4 x int32: [0] = total pairs D               */
+  /* byte offsets inside `bins` */
+  uint64_t off_keys;         /* capacity x uint64: depth_bits<<32 | gaussian id, sorted per tile */
+  uint64_t off_payload;      /* capacity x uint32: pair index within its Gaussian */
+} mgs_workspace_sizes;
+
+typedef struct mgs_forward_args {
+  mgs_raster_shape shape;
+  /* inputs */
+  const float* means3D;         /* [N,3] */
+  const float* scales;          /* [N,3] or NULL when cov3D_precomp is given */
+  const float* rotations;       /* [N,4] (r,x,y,z), used as given */
+  const float* cov3D_precomp;   /* [N,6] or NULL */
+  const float* opacities;       /* [N] */
+  const float* shs;             /* [N,K,3] or NULL when colors_precomp is given */
+  const float* colors_precomp;  /* [N,3] or NULL */
+  const float* viewmatrix;      /* [4,4] = T_w2c^T     (camera_utils.py:94-96)  */
+  const float* projmatrix;      /* [4,4] = view @ proj (camera_utils.py:98-104) */
+  const float* projmatrix_raw;  /* [4,4] projection    (slam_frontend.py:1815-1825) */
+  const float* campos;          /* >= 3 floats */
+  const float* bg;              /* [3] */
+  /* workspaces */
+  void* geom;
+  void* bins;
+  /* outputs */
+  float* out_color;    /* [3,H,W] */
+  float* out_depth;    /* [1,H,W] */
+  float* out_opacity;  /* [1,H,W] */
+  int32_t* radii;      /* [N] */
+  int32_t* n_touched;  /* [N] */
+} mgs_forward_args;
+
+typedef struct mgs_backward_args {
+  mgs_forward_args fwd;        /* same inputs / workspaces as the forward call */
+  const float* grad_color;     /* [3,H,W] */
+  const float* grad_depth;     /* [1,H,W] or NULL */
+  void* bwd;                   /* bwd_bytes of scratch */
+  /* outputs (all overwritten) */
+  float* grad_means3D;         /* [N,3] */
+  float* grad_means2D;         /* [N,3]: (dL/dndc_x, dL/dndc_y, 0) - densification statistic,
+                                  gaussian_model.py:693-697 */
+  float* grad_colors;          /* [N,K,3] when shs, else [N,3] */
+  float* grad_opacities;       /* [N] */
+  float* grad_scales;          /* [N,3] or NULL */
+  float* grad_rotations;       /* [N,4] or NULL */
+  float* grad_cov3D;           /* [N,6] or NULL */
+  float* grad_tau;             /* [6] = [rho(3); theta(3)]: cam_trans_delta, cam_rot_delta
+                                  (pose_utils.py:88-92) */
+  /* sketched pose Jacobian (slam_frontend.py:269-338,654-669); sketch_mode 0 = off */
+  int32_t sketch_mode;
+  int32_t sketch_dim;
+  int32_t stack_dim;
+  const int32_t* sketch_indices;  /* [stack,H,W] slice for this repeat, bucket id or -1 */
+  float* grad_sketch_dtau;        /* [stack,sketch,6] */
+  void* sketch_ws;                /* sketch_bytes of scratch (sketch_mode != 0) */
+} mgs_backward_args;
+
+int32_t mgs_abi_version(void);
+const char* mgs_status_string(int32_t status);
+
+/* Sizes/offsets of the workspaces for `shape` (uses shape->pair_capacity). */
+int32_t mgs_raster_workspace_query(const mgs_raster_shape* shape, mgs_workspace_sizes* out);
+
+/* Forward, stage 1: projection + EWA splat + pair counting + tile scan.
+ * Needs `geom` only.  On return (stream order) counters[0] in geom holds D, the
+ * number of (tile, Gaussian) pairs; radii is final; n_touched is zeroed. */
+int32_t mgs_raster_forward_project(const mgs_forward_args* args, void* stream);
+
+/* Forward, stage 2: pair emission, per-tile depth sort, front-to-back blend.
+ * Safe for any pair_capacity; results are complete iff D <= pair_capacity. */
+int32_t mgs_raster_forward_blend(const mgs_forward_args* args, void* stream);
+
+/* Backward of the whole rasteriser (re-entrant: reads geom/bins, never writes them). */
+int32_t mgs_raster_backward(const mgs_backward_args* args, void* stream);
+
+/* simple-knn: out[i] = mean of the 3 smallest squared distances from points[i] to
+ * the other points (exact).  `scratch` must hold mgs_knn_scratch_bytes(P) bytes. */
+uint64_t mgs_knn_scratch_bytes(int32_t num_points);
+int32_t mgs_knn_dist2(const float* points, int32_t num_points, float* out, void* scratch,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MONOGS_RASTER_H */

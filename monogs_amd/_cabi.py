@@ -1,0 +1,106 @@
+"""ctypes binding of the C ABI in include/monogs_raster.h.
+
+The shared library is built in-tree by `__graft_entry__.build()` (hipcc, gfx950) at
+monogs_amd/lib/libmonogs_raster.so.  There is NO fallback: if the library is missing
+or an entry point is absent, importing `lib()` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmonogs_raster.so")
+
+ABI_VERSION = 1
+
+EXPORTS = (
+    "mgs_abi_version", "mgs_status_string", "mgs_raster_workspace_query",
+    "mgs_raster_forward_project", "mgs_raster_forward_blend", "mgs_raster_backward",
+    "mgs_knn_scratch_bytes", "mgs_knn_dist2",
+)
+
+_fp = C.c_void_p  # device pointers travel as plain addresses
+
+
+class RasterShape(C.Structure):
+    _fields_ = [("num_gaussians", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32),
+                ("pair_capacity", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
+                ("scale_modifier", C.c_float)]
+
+
+class WorkspaceSizes(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "geom_bytes", "bins_bytes", "bwd_bytes", "sketch_bytes", "off_records",
+        "off_pair_count", "off_tile_offset", "off_final_T", "off_n_contrib", "off_counters",
+        "off_keys", "off_payload")]
+
+
+class ForwardArgs(C.Structure):
+    _fields_ = [("shape", RasterShape)] + [(n, _fp) for n in (
+        "means3D", "scales", "rotations", "cov3D_precomp", "opacities", "shs", "colors_precomp",
+        "viewmatrix", "projmatrix", "projmatrix_raw", "campos", "bg", "geom", "bins",
+        "out_color", "out_depth", "out_opacity", "radii", "n_touched")]
+
+
+class BackwardArgs(C.Structure):
+    _fields_ = ([("fwd", ForwardArgs)] + [(n, _fp) for n in (
+        "grad_color", "grad_depth", "bwd", "grad_means3D", "grad_means2D", "grad_colors",
+        "grad_opacities", "grad_scales", "grad_rotations", "grad_cov3D", "grad_tau")]
+        + [("sketch_mode", C.c_int32), ("sketch_dim", C.c_int32), ("stack_dim", C.c_int32),
+           ("sketch_indices", _fp), ("grad_sketch_dtau", _fp), ("sketch_ws", _fp)])
+
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the native library; raise loudly if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback.")
+    L = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(L, name):
+            raise NativeLibraryError(f"{LIB_PATH} does not export {name}")
+    L.mgs_abi_version.restype = C.c_int32
+    L.mgs_status_string.restype = C.c_char_p
+    L.mgs_status_string.argtypes = [C.c_int32]
+    L.mgs_raster_workspace_query.restype = C.c_int32
+    L.mgs_raster_workspace_query.argtypes = [C.POINTER(RasterShape), C.POINTER(WorkspaceSizes)]
+    for fn in (L.mgs_raster_forward_project, L.mgs_raster_forward_blend):
+        fn.restype = C.c_int32
+        fn.argtypes = [C.POINTER(ForwardArgs), C.c_void_p]
+    L.mgs_raster_backward.restype = C.c_int32
+    L.mgs_raster_backward.argtypes = [C.POINTER(BackwardArgs), C.c_void_p]
+    L.mgs_knn_scratch_bytes.restype = C.c_uint64
+    L.mgs_knn_scratch_bytes.argtypes = [C.c_int32]
+    L.mgs_knn_dist2.restype = C.c_int32
+    L.mgs_knn_dist2.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    if L.mgs_abi_version() != ABI_VERSION:
+        raise NativeLibraryError(
+            f"ABI mismatch: library {L.mgs_abi_version()} vs binding {ABI_VERSION}")
+    _lib = L
+    return L
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = lib().mgs_status_string(status).decode()
+        raise RuntimeError(f"{what} failed: {msg} (status {status})")
+
+
+def workspace_sizes(shape: RasterShape) -> WorkspaceSizes:
+    out = WorkspaceSizes()
+    check(lib().mgs_raster_workspace_query(C.byref(shape), C.byref(out)),
+          "mgs_raster_workspace_query")
+    return out

@@ -1,0 +1,142 @@
+// extern "C" entry points declared in include/monogs_raster.h.
+#include "raster_kernels.h"
+
+namespace mgs {
+int launch_forward_project(const KP& P, hipStream_t st);
+int launch_forward_blend(const KP& P, hipStream_t st);
+int launch_backward(const KP& P, const KB& B, hipStream_t st);
+int launch_knn(const float* pts, int n, float* out, hipStream_t st);
+}  // namespace mgs
+
+using namespace mgs;
+
+namespace {
+
+bool shape_ok(const mgs_raster_shape& s) {
+  return s.num_gaussians >= 1 && s.width >= 1 && s.height >= 1 && s.sh_degree >= 0 &&
+         s.sh_degree <= 3 && s.tanfovx > 0.f && s.tanfovy > 0.f && s.pair_capacity >= 0;
+}
+
+int fill_kp(const mgs_forward_args& a, bool need_bins, bool need_outputs, KP& P) {
+  const mgs_raster_shape& s = a.shape;
+  if (!shape_ok(s)) return MGS_ERR_BAD_ARGUMENT;
+  if (!a.means3D || !a.opacities || !a.viewmatrix || !a.projmatrix || !a.projmatrix_raw ||
+      !a.campos || !a.bg || !a.geom)
+    return MGS_ERR_BAD_ARGUMENT;
+  if (!a.cov3D_precomp && (!a.scales || !a.rotations)) return MGS_ERR_BAD_ARGUMENT;
+  if (!a.shs && !a.colors_precomp) return MGS_ERR_BAD_ARGUMENT;
+  if (a.shs && s.sh_coeffs < (s.sh_degree + 1) * (s.sh_degree + 1)) return MGS_ERR_BAD_ARGUMENT;
+  if (need_bins && s.pair_capacity > 0 && !a.bins) return MGS_ERR_BAD_ARGUMENT;
+  if (need_outputs &&
+      (!a.out_color || !a.out_depth || !a.out_opacity || !a.radii || !a.n_touched))
+    return MGS_ERR_BAD_ARGUMENT;
+  const Layout L = make_layout(s);
+  P.N = s.num_gaussians; P.W = s.width; P.H = s.height;
+  P.grid_x = (s.width + kTile - 1) / kTile; P.grid_y = (s.height + kTile - 1) / kTile;
+  P.T = P.grid_x * P.grid_y;
+  P.deg = s.sh_degree; P.K = a.shs ? s.sh_coeffs : 0; P.cap = s.pair_capacity;
+  P.tanfovx = s.tanfovx; P.tanfovy = s.tanfovy;
+  P.focal_x = s.width / (2.0f * s.tanfovx); P.focal_y = s.height / (2.0f * s.tanfovy);
+  P.mod = s.scale_modifier;
+  P.means = a.means3D; P.scales = a.cov3D_precomp ? nullptr : a.scales;
+  P.rots = a.cov3D_precomp ? nullptr : a.rotations; P.covp = a.cov3D_precomp;
+  P.opac = a.opacities; P.shs = a.colors_precomp ? nullptr : a.shs; P.precol = a.colors_precomp;
+  P.V = a.viewmatrix; P.PM = a.projmatrix; P.Praw = a.projmatrix_raw; P.campos = a.campos;
+  P.bg = a.bg;
+  char* g = (char*)a.geom;
+  P.rec = (SplatRec*)(g + L.rec);
+  P.pair_count = (int*)(g + L.pair_count);
+  P.tile_count = (int*)(g + L.tile_count);
+  P.tile_offset = (int*)(g + L.tile_offset);
+  P.tile_cursor = (int*)(g + L.tile_cursor);
+  P.final_T = (float*)(g + L.final_T);
+  P.n_contrib = (int*)(g + L.n_contrib);
+  P.counters = (int*)(g + L.counters);
+  char* b = (char*)a.bins;
+  P.keys = b ? (unsigned long long*)(b + L.keys) : nullptr;
+  P.payload = b ? (unsigned int*)(b + L.payload) : nullptr;
+  P.out_color = a.out_color; P.out_depth = a.out_depth; P.out_opacity = a.out_opacity;
+  P.radii = a.radii; P.n_touched = a.n_touched;
+  return MGS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t mgs_abi_version(void) { return MGS_ABI_VERSION; }
+
+const char* mgs_status_string(int32_t status) {
+  switch (status) {
+    case MGS_OK: return "ok";
+    case MGS_ERR_BAD_ARGUMENT: return "bad argument (null pointer, non-positive size or unsupported degree)";
+    case MGS_ERR_LAUNCH: return "kernel launch failed (hipGetLastError != hipSuccess)";
+    case MGS_ERR_UNSUPPORTED: return "unsupported configuration";
+    default: return "unknown status";
+  }
+}
+
+int32_t mgs_raster_workspace_query(const mgs_raster_shape* shape, mgs_workspace_sizes* out) {
+  if (!shape || !out || !shape_ok(*shape)) return MGS_ERR_BAD_ARGUMENT;
+  const Layout L = make_layout(*shape);
+  out->geom_bytes = L.geom_bytes; out->bins_bytes = L.bins_bytes; out->bwd_bytes = L.bwd_bytes;
+  out->sketch_bytes = L.sketch_bytes;
+  out->off_records = L.rec; out->off_pair_count = L.pair_count;
+  out->off_tile_offset = L.tile_offset; out->off_final_T = L.final_T;
+  out->off_n_contrib = L.n_contrib; out->off_counters = L.counters;
+  out->off_keys = L.keys; out->off_payload = L.payload;
+  return MGS_OK;
+}
+
+int32_t mgs_raster_forward_project(const mgs_forward_args* args, void* stream) {
+  if (!args) return MGS_ERR_BAD_ARGUMENT;
+  KP P;
+  const int rc = fill_kp(*args, false, true, P);
+  if (rc != MGS_OK) return rc;
+  return launch_forward_project(P, (hipStream_t)stream);
+}
+
+int32_t mgs_raster_forward_blend(const mgs_forward_args* args, void* stream) {
+  if (!args) return MGS_ERR_BAD_ARGUMENT;
+  KP P;
+  const int rc = fill_kp(*args, true, true, P);
+  if (rc != MGS_OK) return rc;
+  return launch_forward_blend(P, (hipStream_t)stream);
+}
+
+int32_t mgs_raster_backward(const mgs_backward_args* args, void* stream) {
+  if (!args) return MGS_ERR_BAD_ARGUMENT;
+  KP P;
+  const int rc = fill_kp(args->fwd, true, false, P);
+  if (rc != MGS_OK) return rc;
+  if (!args->grad_color || !args->bwd || !args->grad_means3D || !args->grad_means2D ||
+      !args->grad_colors || !args->grad_opacities || !args->grad_tau)
+    return MGS_ERR_BAD_ARGUMENT;
+  if (args->sketch_mode != 0) return MGS_ERR_UNSUPPORTED;
+  const Layout L = make_layout(args->fwd.shape);
+  KB B;
+  B.grad_color = args->grad_color; B.grad_depth = args->grad_depth;
+  char* w = (char*)args->bwd;
+  B.pair_grad = (float4*)(w + L.pair_grad);
+  B.pair_base = (int*)(w + L.pair_base);
+  B.block_sums = (int*)(w + L.block_sums);
+  B.tau_partial = (float*)(w + L.tau_partial);
+  B.g_means3D = args->grad_means3D; B.g_means2D = args->grad_means2D;
+  B.g_colors = args->grad_colors; B.g_opac = args->grad_opacities;
+  B.g_scales = args->grad_scales; B.g_rots = args->grad_rotations; B.g_cov = args->grad_cov3D;
+  B.g_tau = args->grad_tau;
+  B.sketch_mode = 0; B.sketch_dim = 0; B.stack_dim = 0; B.sketch_idx = nullptr;
+  B.g_sketch = nullptr; B.pix_jac = nullptr; B.splat_jac = nullptr;
+  return launch_backward(P, B, (hipStream_t)stream);
+}
+
+uint64_t mgs_knn_scratch_bytes(int32_t num_points) { (void)num_points; return 256; }
+
+int32_t mgs_knn_dist2(const float* points, int32_t num_points, float* out, void* scratch,
+                      void* stream) {
+  (void)scratch;
+  if (!points || !out || num_points < 1) return MGS_ERR_BAD_ARGUMENT;
+  return launch_knn(points, num_points, out, (hipStream_t)stream);
+}
+
+}  // extern "C"

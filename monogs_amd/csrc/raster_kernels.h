@@ -1,0 +1,99 @@
+// Kernel-side parameter blocks and workspace layout shared by the .hip translation
+// units.  Host-only callers use include/monogs_raster.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/monogs_raster.h"
+#include "raster_math.h"
+
+namespace mgs {
+
+// One struct carries everything a forward or backward kernel may need; it is passed
+// by value (kernarg segment -> SGPRs).
+struct KP {
+  int N, W, H, grid_x, grid_y, T, deg, K, cap;
+  float tanfovx, tanfovy, focal_x, focal_y, mod;
+  const float *means, *scales, *rots, *covp, *opac, *shs, *precol;
+  const float *V, *PM, *Praw, *campos, *bg;
+  // geom workspace
+  SplatRec* rec;
+  int* pair_count;
+  int* tile_count;
+  int* tile_offset;
+  int* tile_cursor;
+  float* final_T;
+  int* n_contrib;
+  int* counters;
+  // bins workspace
+  unsigned long long* keys;
+  unsigned int* payload;
+  // forward outputs
+  float *out_color, *out_depth, *out_opacity;
+  int *radii, *n_touched;
+};
+
+struct KB {   // backward extras
+  const float *grad_color, *grad_depth;
+  float4* pair_grad;       // cap x 3 float4
+  int* pair_base;          // N+1
+  int* block_sums;         // scan scratch
+  float* tau_partial;      // nblocks x 6
+  float *g_means3D, *g_means2D, *g_colors, *g_opac, *g_scales, *g_rots, *g_cov, *g_tau;
+  int sketch_mode, sketch_dim, stack_dim;
+  const int* sketch_idx;
+  float* g_sketch;
+  float* pix_jac;          // W*H x 6 per-pixel pose-Jacobian rows (sketch mode)
+  float* splat_jac;        // N x 36 per-splat d(xy,conic,depth)/dtau (sketch mode)
+};
+
+constexpr uint64_t kAlign = 256;
+inline uint64_t align_up(uint64_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
+
+struct Layout {
+  uint64_t rec, pair_count, tile_count, tile_offset, tile_cursor, final_T, n_contrib, counters,
+      geom_bytes;
+  uint64_t keys, payload, bins_bytes;
+  uint64_t pair_grad, pair_base, block_sums, tau_partial, bwd_bytes;
+  uint64_t pix_jac, splat_jac, sketch_bytes;
+};
+
+constexpr int kScanBlock = 2048;   // elements per block in the pair_base scan
+constexpr int kPreBlock = 256;
+
+inline Layout make_layout(const mgs_raster_shape& s) {
+  Layout L;
+  const uint64_t N = (uint64_t)s.num_gaussians;
+  const uint64_t gx = (s.width + kTile - 1) / kTile, gy = (s.height + kTile - 1) / kTile;
+  const uint64_t T = gx * gy, HW = (uint64_t)s.width * s.height;
+  const uint64_t cap = (uint64_t)(s.pair_capacity > 0 ? s.pair_capacity : 0);
+  uint64_t o = 0;
+  L.rec = o; o = align_up(o + N * sizeof(SplatRec));
+  L.pair_count = o; o = align_up(o + N * 4);
+  L.tile_count = o; o = align_up(o + T * 4);
+  L.tile_offset = o; o = align_up(o + (T + 1) * 4);
+  L.tile_cursor = o; o = align_up(o + T * 4);
+  L.final_T = o; o = align_up(o + HW * 4);
+  L.n_contrib = o; o = align_up(o + HW * 4);
+  L.counters = o; o = align_up(o + 16);
+  L.geom_bytes = o;
+  o = 0;
+  L.keys = o; o = align_up(o + cap * 8);
+  L.payload = o; o = align_up(o + cap * 4);
+  L.bins_bytes = o;
+  o = 0;
+  L.pair_grad = o; o = align_up(o + cap * 48);
+  L.pair_base = o; o = align_up(o + (N + 1) * 4);
+  const uint64_t nscan = (N + kScanBlock - 1) / kScanBlock;
+  L.block_sums = o; o = align_up(o + (nscan + 1) * 4);
+  const uint64_t npre = (N + kPreBlock - 1) / kPreBlock;
+  L.tau_partial = o; o = align_up(o + npre * 6 * 4);
+  L.bwd_bytes = o;
+  o = 0;
+  L.pix_jac = o; o = align_up(o + HW * 6 * 4);
+  L.splat_jac = o; o = align_up(o + N * 36 * 4);
+  L.sketch_bytes = o;
+  return L;
+}
+
+}  // namespace mgs

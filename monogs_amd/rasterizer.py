@@ -1,0 +1,250 @@
+"""Host-side mirror of the `diff_gaussian_rasterization` Python package that MonoGS
+imports (`gaussian_splatting/gaussian_renderer/__init__.py:15-18` in the reference
+tree): `GaussianRasterizationSettings`, `GaussianRasterizer`, and the autograd
+Function underneath.  Same names, argument meaning and error behaviour; all compute
+goes through the C ABI in include/monogs_raster.h (HIP kernels for gfx950).
+
+PyTorch is used for device memory (caching allocator), the current HIP stream and
+autograd bookkeeping only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _cabi
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    """Field order as constructed at gaussian_renderer/__init__.py:61-75."""
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    projmatrix_raw: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+# pair-capacity high-water mark per device: the blend stage is launched optimistically
+# with this capacity while the host waits (concurrently) for the true pair count.
+_capacity_hint: dict = {}
+last_stats: dict = {}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _f32c(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _stream_ptr(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _round_cap(n: int) -> int:
+    return max(1024, (int(n * 1.25) + 1023) // 1024 * 1024)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                cov3Ds_precomp, theta, rho, raster_settings, sketch_mode, sketch_dim, stack_dim,
+                sketch_dtau, sketch_indices):
+        st = raster_settings
+        dev = means3D.device
+        if dev.type != "cuda":
+            raise RuntimeError(
+                "monogs_amd rasteriser runs on the GPU only (HIP kernels, gfx950); "
+                f"got tensors on {dev}. There is no CPU fallback.")
+        lib = _cabi.lib()
+        N = int(means3D.shape[0])
+        H, W = int(st.image_height), int(st.image_width)
+        means3D_c = _f32c(means3D)
+        sh_c = _f32c(sh) if sh is not None and sh.numel() else None
+        col_c = _f32c(colors_precomp) if colors_precomp is not None and colors_precomp.numel() else None
+        op_c = _f32c(opacities).reshape(-1)
+        cov_c = _f32c(cov3Ds_precomp) if cov3Ds_precomp is not None and cov3Ds_precomp.numel() else None
+        sc_c = _f32c(scales) if scales is not None and scales.numel() else None
+        rot_c = _f32c(rotations) if rotations is not None and rotations.numel() else None
+        view = _f32c(st.viewmatrix.to(dev))
+        proj = _f32c(st.projmatrix.to(dev))
+        praw = _f32c(st.projmatrix_raw.to(dev))
+        campos = _f32c(st.campos.to(dev)).reshape(-1)
+        bg = _f32c(st.bg.to(dev)).reshape(-1)
+        K = int(sh_c.shape[1]) if sh_c is not None else 0
+
+        hint = _capacity_hint.get(dev.index)
+        shape = _cabi.RasterShape(N, W, H, int(st.sh_degree), K, int(hint or 0),
+                                  float(st.tanfovx), float(st.tanfovy), float(st.scale_modifier))
+        sizes = _cabi.workspace_sizes(shape)
+        geom = torch.empty(int(sizes.geom_bytes), dtype=torch.uint8, device=dev)
+        color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+        depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+        opacity = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+        radii = torch.empty(N, dtype=torch.int32, device=dev)
+        n_touched = torch.empty(N, dtype=torch.int32, device=dev)
+
+        a = _cabi.ForwardArgs()
+        a.shape = shape
+        a.means3D, a.scales, a.rotations = _ptr(means3D_c), _ptr(sc_c), _ptr(rot_c)
+        a.cov3D_precomp, a.opacities = _ptr(cov_c), _ptr(op_c)
+        a.shs, a.colors_precomp = _ptr(sh_c), _ptr(col_c)
+        a.viewmatrix, a.projmatrix, a.projmatrix_raw = _ptr(view), _ptr(proj), _ptr(praw)
+        a.campos, a.bg = _ptr(campos), _ptr(bg)
+        a.geom, a.bins = _ptr(geom), None
+        a.out_color, a.out_depth, a.out_opacity = _ptr(color), _ptr(depth), _ptr(opacity)
+        a.radii, a.n_touched = _ptr(radii), _ptr(n_touched)
+        stream = _stream_ptr(dev)
+
+        _cabi.check(lib.mgs_raster_forward_project(C.byref(a), stream), "mgs_raster_forward_project")
+        off = int(sizes.off_counters)
+        counter = geom[off:off + 4].view(torch.int32)
+        host_cnt = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        host_cnt.copy_(counter, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+
+        def run_blend(cap):
+            shape.pair_capacity = cap
+            a.shape = shape
+            sz = _cabi.workspace_sizes(shape)
+            bins_ = torch.empty(int(sz.bins_bytes), dtype=torch.uint8, device=dev)
+            a.bins = _ptr(bins_)
+            _cabi.check(lib.mgs_raster_forward_blend(C.byref(a), stream), "mgs_raster_forward_blend")
+            return bins_
+
+        bins = None
+        retried = False
+        if hint:
+            bins = run_blend(int(hint))      # optimistic: overlaps the host wait below
+        ev.synchronize()
+        D = int(host_cnt.item())
+        if bins is None or D > shape.pair_capacity:
+            retried = bins is not None
+            bins = run_blend(_round_cap(D))
+        _capacity_hint[dev.index] = max(_round_cap(D), int(shape.pair_capacity))
+        last_stats.update(pairs=D, capacity=int(shape.pair_capacity), retried=retried, N=N)
+
+        ctx.raster_settings = st
+        ctx.shape_tuple = (N, W, H, int(st.sh_degree), K, int(shape.pair_capacity))
+        ctx.sketch = (int(sketch_mode), int(sketch_dim), int(stack_dim))
+        ctx.sketch_indices = sketch_indices
+        ctx.repeat_iter = 0
+        ctx.op_shape = tuple(opacities.shape)
+        ctx.has = (sh_c is not None, col_c is not None, sc_c is not None, rot_c is not None,
+                   cov_c is not None)
+        ctx.save_for_backward(means3D_c, sh_c, col_c, op_c, sc_c, rot_c, cov_c, view, proj, praw,
+                              campos, bg, geom, bins)
+        ctx.mark_non_differentiable(radii, n_touched)
+        return color, radii, depth, opacity, n_touched
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth, grad_opacity, grad_n_touched):
+        (means3D, sh, col, op, sc, rot, cov, view, proj, praw, campos, bg, geom,
+         bins) = ctx.saved_tensors
+        st = ctx.raster_settings
+        dev = means3D.device
+        lib = _cabi.lib()
+        N, W, H, deg, K, cap = ctx.shape_tuple
+        shape = _cabi.RasterShape(N, W, H, deg, K, cap, float(st.tanfovx), float(st.tanfovy),
+                                  float(st.scale_modifier))
+        sizes = _cabi.workspace_sizes(shape)
+        bwd_ws = torch.empty(int(sizes.bwd_bytes), dtype=torch.uint8, device=dev)
+        g_means3D = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        g_means2D = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        g_colors = (torch.empty(N, K, 3, dtype=torch.float32, device=dev) if sh is not None
+                    else torch.empty(N, 3, dtype=torch.float32, device=dev))
+        g_op = torch.empty(N, dtype=torch.float32, device=dev)
+        g_sc = torch.empty(N, 3, dtype=torch.float32, device=dev) if sc is not None else None
+        g_rot = torch.empty(N, 4, dtype=torch.float32, device=dev) if rot is not None else None
+        g_cov = torch.empty(N, 6, dtype=torch.float32, device=dev) if cov is not None else None
+        g_tau = torch.empty(6, dtype=torch.float32, device=dev)
+        gc = _f32c(grad_color) if grad_color is not None else torch.zeros(3, H, W, device=dev)
+        gd = _f32c(grad_depth) if grad_depth is not None else None
+
+        b = _cabi.BackwardArgs()
+        f = b.fwd
+        f.shape = shape
+        f.means3D, f.scales, f.rotations = _ptr(means3D), _ptr(sc), _ptr(rot)
+        f.cov3D_precomp, f.opacities = _ptr(cov), _ptr(op)
+        f.shs, f.colors_precomp = _ptr(sh), _ptr(col)
+        f.viewmatrix, f.projmatrix, f.projmatrix_raw = _ptr(view), _ptr(proj), _ptr(praw)
+        f.campos, f.bg = _ptr(campos), _ptr(bg)
+        f.geom, f.bins = _ptr(geom), _ptr(bins)
+        b.grad_color, b.grad_depth, b.bwd = _ptr(gc), _ptr(gd), _ptr(bwd_ws)
+        b.grad_means3D, b.grad_means2D = _ptr(g_means3D), _ptr(g_means2D)
+        b.grad_colors, b.grad_opacities = _ptr(g_colors), _ptr(g_op)
+        b.grad_scales, b.grad_rotations, b.grad_cov3D = _ptr(g_sc), _ptr(g_rot), _ptr(g_cov)
+        b.grad_tau = _ptr(g_tau)
+        sketch_mode, sketch_dim, stack_dim = ctx.sketch
+        g_sketch = None
+        keep = []
+        if sketch_mode != 0:
+            idx_all = ctx.sketch_indices
+            idx = idx_all[ctx.repeat_iter].contiguous()   # [stack,H,W] int32
+            ctx.repeat_iter += 1
+            g_sketch = torch.empty(stack_dim, sketch_dim, 6, dtype=torch.float32, device=dev)
+            sk_ws = torch.empty(int(sizes.sketch_bytes), dtype=torch.uint8, device=dev)
+            keep += [idx, sk_ws]
+            b.sketch_mode, b.sketch_dim, b.stack_dim = sketch_mode, sketch_dim, stack_dim
+            b.sketch_indices, b.grad_sketch_dtau, b.sketch_ws = _ptr(idx), _ptr(g_sketch), _ptr(sk_ws)
+        _cabi.check(lib.mgs_raster_backward(C.byref(b), _stream_ptr(dev)), "mgs_raster_backward")
+
+        has_sh, has_col, _, _, _ = ctx.has
+        return (g_means3D, g_means2D, g_colors if has_sh else None,
+                g_colors if has_col else None, g_op.reshape(ctx.op_shape), g_sc, g_rot, g_cov,
+                g_tau[3:], g_tau[:3], None, None, None, None, g_sketch, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                        cov3Ds_precomp, theta, rho, raster_settings, sketch_mode=0, sketch_dim=0,
+                        stack_dim=0, sketch_dtau=None, sketch_indices=None):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales,
+                                     rotations, cov3Ds_precomp, theta, rho, raster_settings,
+                                     sketch_mode, sketch_dim, stack_dim, sketch_dtau,
+                                     sketch_indices)
+
+
+class GaussianRasterizer(nn.Module):
+    """Callable with the 16 keyword arguments used at
+    gaussian_renderer/__init__.py:151-168; returns
+    (rendered_image, radii, depth, opacity, n_touched)."""
+
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,
+                rotations=None, cov3D_precomp=None, theta=None, rho=None,
+                num_backward_gaussians=-1, sketch_mode=0, sketch_dim=0, stack_dim=0,
+                sketch_dtau=None, sketch_indices=None):
+        if (shs is None) == (colors_precomp is None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+                (scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception(
+                "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        dev = means3D.device
+        if theta is None:
+            theta = torch.zeros(3, dtype=torch.float32, device=dev)
+        if rho is None:
+            rho = torch.zeros(3, dtype=torch.float32, device=dev)
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales,
+                                   rotations, cov3D_precomp, theta, rho, self.raster_settings,
+                                   sketch_mode, sketch_dim, stack_dim, sketch_dtau, sketch_indices)

@@ -1,0 +1,395 @@
+"""CPU oracle for the differentiable Gaussian rasteriser (TEST INFRASTRUCTURE ONLY).
+
+This file is a from-scratch PyTorch restatement of the *contract* of the
+`diff_gaussian_rasterization` extension that MonoGS calls at
+`gaussian_splatting/gaussian_renderer/__init__.py:61-75,151-168` (reference tree
+paths are relative to /root/reference).  The extension's own CUDA source is an
+un-vendored git submodule (`.gitmodules:4-7`,
+github.com/rogerhh/diff-gaussian-rasterization-w-pose, branch main, commit
+unpinned) and is ABSENT from the reference tree, so the algorithm restated here
+follows the published 3DGS / MonoGS algorithm and the in-tree call sites and
+consumers; every behavioural constant is listed in `CONSTANTS` below.
+
+PARITY UNPINNED: the reference holds no golden vector, test or fixture for the
+rasteriser.  What *is* pinned against the reference's own code
+(see tests/golden/make_golden.py) are the pieces that exist in-tree: the camera
+matrices (`utils/camera_utils.py:94-104`, `graphics_utils.py:56-77`), the 3-D
+covariance (`general_utils.py:114-149`), SH evaluation (`sh_utils.py:55-118`),
+SE(3) exponential (`utils/pose_utils.py:26-74`) and the tracking / mapping
+losses (`utils/slam_utils.py:58-75,188-253`).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The product path (monogs_amd/) never does.
+
+Gradients come from torch autograd (never hand-derived) with two deliberate,
+documented deviations from plain autograd that mirror the reference extension:
+  * the alpha cap `min(0.99, o*G)` is straight-through in backward,
+  * the `opacity` output carries no gradient (the extension's backward receives
+    only grad_out_color and grad_out_depth).
+"""
+from __future__ import annotations
+
+import math
+from typing import NamedTuple, Optional
+
+import torch
+
+CONSTANTS = dict(
+    near_z=0.2,            # cull if p_view.z <= 0.2
+    fov_clamp=1.3,         # clamp t.x/t.z to +-1.3*tanfov in the EWA Jacobian
+    lowpass=0.3,           # +0.3 px^2 on the 2-D covariance diagonal
+    radius_sigma=3.0,      # radius = ceil(3*sqrt(lambda_max))
+    lambda_floor=0.1,      # sqrt(max(0.1, mid^2-det))
+    alpha_min=1.0 / 255.0,  # skip alpha < 1/255
+    alpha_max=0.99,        # cap alpha
+    t_stop=1e-4,           # stop when T*(1-alpha) < 1e-4
+    touch_t=0.5,           # n_touched counts contributions with T*(1-alpha) > 0.5
+    tile=16,               # 16x16 pixel tiles
+    w_eps=1e-7,            # p_w = 1/(p_hom.w + 1e-7)
+)
+
+SH_C0 = 0.28209479177387814
+SH_C1 = 0.4886025119029199
+SH_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005,
+         -1.0925484305920792, 0.5462742152960396)
+SH_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658,
+         0.3731763325901154, -0.4570457994644658, 1.445305721320277,
+         -0.5900435899266435)
+
+
+class RasterSettings(NamedTuple):
+    """Field order of `GaussianRasterizationSettings`
+    (gaussian_renderer/__init__.py:61-75)."""
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    projmatrix_raw: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+# --------------------------------------------------------------------------- #
+# SE(3) helpers (restated from utils/pose_utils.py:13-74; pinned by golden)
+# --------------------------------------------------------------------------- #
+def skew(x: torch.Tensor) -> torch.Tensor:
+    z = torch.zeros((), dtype=x.dtype)
+    return torch.stack([
+        torch.stack([z, -x[2], x[1]]),
+        torch.stack([x[2], z, -x[0]]),
+        torch.stack([-x[1], x[0], z]),
+    ])
+
+
+def so3_exp(theta: torch.Tensor) -> torch.Tensor:
+    W = skew(theta)
+    W2 = W @ W
+    angle = torch.linalg.norm(theta)
+    I = torch.eye(3, dtype=theta.dtype)
+    if float(angle.detach()) < 1e-5:
+        return I + W + 0.5 * W2
+    return I + (torch.sin(angle) / angle) * W + ((1 - torch.cos(angle)) / angle ** 2) * W2
+
+
+def so3_V(theta: torch.Tensor) -> torch.Tensor:
+    W = skew(theta)
+    W2 = W @ W
+    angle = torch.linalg.norm(theta)
+    I = torch.eye(3, dtype=theta.dtype)
+    if float(angle.detach()) < 1e-5:
+        return I + 0.5 * W + (1.0 / 6.0) * W2
+    return (I + W * ((1.0 - torch.cos(angle)) / angle ** 2)
+            + W2 * ((angle - torch.sin(angle)) / angle ** 3))
+
+
+def se3_exp(tau: torch.Tensor) -> torch.Tensor:
+    """tau = [rho(3); theta(3)] -> 4x4 (pose_utils.py:62-74)."""
+    rho, theta = tau[:3], tau[3:]
+    R = so3_exp(theta)
+    t = so3_V(theta) @ rho
+    top = torch.cat([R, t[:, None]], dim=1)
+    bottom = torch.tensor([[0.0, 0.0, 0.0, 1.0]], dtype=tau.dtype)
+    return torch.cat([top, bottom], dim=0)
+
+
+# --------------------------------------------------------------------------- #
+# per-Gaussian stage
+# --------------------------------------------------------------------------- #
+def quat_to_rot(q: torch.Tensor, normalize: bool = False) -> torch.Tensor:
+    """(r,x,y,z) -> R, the polynomial of general_utils.py:114-136.  The Python
+    helper normalises first; the extension receives `get_rotation` (already
+    normalised, gaussian_model.py:83-84) and applies the polynomial to q as given
+    [UPSTREAM-KNOWLEDGE], hence normalize=False on the rasteriser path."""
+    if normalize:
+        q = q / torch.linalg.norm(q, dim=1, keepdim=True)
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.stack([
+        1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+        2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+        2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y),
+    ], dim=1).reshape(-1, 3, 3)
+    return R
+
+
+def cov3d_from_scale_rot(scales, rotations, scale_modifier):
+    """Sigma = R S S^T R^T, returned as full [N,3,3]
+    (general_utils.py:139-149 + gaussian_model.py:54-58)."""
+    R = quat_to_rot(rotations)
+    L = R * (scales * scale_modifier)[:, None, :]
+    return L @ L.transpose(1, 2)
+
+
+def cov3d_from_packed(c6):
+    """[N,6] upper-triangular packing (general_utils.py:98-111) -> [N,3,3]."""
+    xx, xy, xz, yy, yz, zz = c6.unbind(dim=1)
+    return torch.stack([xx, xy, xz, xy, yy, yz, xz, yz, zz], dim=1).reshape(-1, 3, 3)
+
+
+def eval_sh_color(deg, shs, dirs):
+    """shs [N,K,3] (gaussian_model.py:89-93 layout), dirs [N,3] unit.
+    Same polynomial as sh_utils.py:55-118 (degrees 0..3)."""
+    res = SH_C0 * shs[:, 0]
+    if deg > 0:
+        x, y, z = dirs[:, 0:1], dirs[:, 1:2], dirs[:, 2:3]
+        res = res - SH_C1 * y * shs[:, 1] + SH_C1 * z * shs[:, 2] - SH_C1 * x * shs[:, 3]
+        if deg > 1:
+            xx, yy, zz = x * x, y * y, z * z
+            xy, yz, xz = x * y, y * z, x * z
+            res = (res + SH_C2[0] * xy * shs[:, 4] + SH_C2[1] * yz * shs[:, 5]
+                   + SH_C2[2] * (2.0 * zz - xx - yy) * shs[:, 6]
+                   + SH_C2[3] * xz * shs[:, 7] + SH_C2[4] * (xx - yy) * shs[:, 8])
+            if deg > 2:
+                res = (res + SH_C3[0] * y * (3 * xx - yy) * shs[:, 9]
+                       + SH_C3[1] * xy * z * shs[:, 10]
+                       + SH_C3[2] * y * (4 * zz - xx - yy) * shs[:, 11]
+                       + SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * shs[:, 12]
+                       + SH_C3[4] * x * (4 * zz - xx - yy) * shs[:, 13]
+                       + SH_C3[5] * z * (xx - yy) * shs[:, 14]
+                       + SH_C3[6] * x * (xx - 3 * yy) * shs[:, 15])
+    return res
+
+
+class Projected(NamedTuple):
+    xy: torch.Tensor          # [N,2] pixel coordinates of the mean
+    conic: torch.Tensor       # [N,3] inverse 2-D covariance (A, B, C)
+    depth: torch.Tensor       # [N]   p_view.z
+    rgb: torch.Tensor         # [N,3]
+    opacity: torch.Tensor     # [N]
+    radii: torch.Tensor       # [N] int32, 0 when culled
+    rect_min: torch.Tensor    # [N,2] int32 tile rect (inclusive)
+    rect_max: torch.Tensor    # [N,2] int32 tile rect (exclusive)
+    cov2d: torch.Tensor       # [N,3] (a,b,c) after the low-pass, for stage tests
+
+
+def project(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+            cov3D_precomp, settings: RasterSettings, tau: Optional[torch.Tensor]):
+    """Per-Gaussian projection + EWA splat (contract rows a4)."""
+    K = CONSTANTS
+    dt = means3D.dtype
+    H, W = int(settings.image_height), int(settings.image_width)
+    V = settings.viewmatrix.to(dt)
+    Praw = settings.projmatrix_raw.to(dt)
+    if tau is not None:
+        # left perturbation T_new = Exp(tau) * T_w2c, evaluated at tau = 0
+        # (pose_utils.py:88-98); values of theta/rho are ignored by the forward
+        # exactly as the extension ignores them.
+        tau0 = tau - tau.detach()
+        T = se3_exp(tau0) @ V.t()
+        V = T.t()
+        PM = V @ Praw
+    else:
+        PM = settings.projmatrix.to(dt)
+
+    N = means3D.shape[0]
+    ones = torch.ones(N, 1, dtype=dt)
+    p_h = torch.cat([means3D, ones], dim=1)
+    p_view = (p_h @ V)[:, :3]
+    p_hom = p_h @ PM
+    p_w = 1.0 / (p_hom[:, 3] + K["w_eps"])
+    p_proj = p_hom[:, :3] * p_w[:, None]
+    ndc = p_proj[:, :2]
+    if means2D is not None:
+        ndc = ndc + means2D[:, :2]   # dummy leaf: its grad is dL/d(ndc)
+    px = ((ndc[:, 0] + 1.0) * W - 1.0) * 0.5
+    py = ((ndc[:, 1] + 1.0) * H - 1.0) * 0.5
+    xy = torch.stack([px, py], dim=1)
+
+    depth = p_view[:, 2]
+    in_front = depth > K["near_z"]
+
+    if cov3D_precomp is not None:
+        Sigma = cov3d_from_packed(cov3D_precomp)
+    else:
+        Sigma = cov3d_from_scale_rot(scales, rotations, float(settings.scale_modifier))
+
+    focal_x = W / (2.0 * settings.tanfovx)
+    focal_y = H / (2.0 * settings.tanfovy)
+    tz = torch.where(in_front, depth, torch.ones_like(depth))  # keep culled rows finite
+    limx, limy = K["fov_clamp"] * settings.tanfovx, K["fov_clamp"] * settings.tanfovy
+    tx = torch.clamp(p_view[:, 0] / tz, -limx, limx) * tz
+    ty = torch.clamp(p_view[:, 1] / tz, -limy, limy) * tz
+    zero = torch.zeros_like(tz)
+    J = torch.stack([
+        focal_x / tz, zero, -(focal_x * tx) / (tz * tz),
+        zero, focal_y / tz, -(focal_y * ty) / (tz * tz),
+    ], dim=1).reshape(N, 2, 3)
+    Rw2c = V[:3, :3].t()                      # p_view = Rw2c p + t
+    M = J @ Rw2c                               # [N,2,3]
+    cov = M @ Sigma @ M.transpose(1, 2)        # [N,2,2]
+    a = cov[:, 0, 0] + K["lowpass"]
+    b = cov[:, 0, 1]
+    c = cov[:, 1, 1] + K["lowpass"]
+    det = a * c - b * b
+    det_ok = det != 0
+    det_s = torch.where(det_ok, det, torch.ones_like(det))
+    conic = torch.stack([c / det_s, -b / det_s, a / det_s], dim=1)
+
+    with torch.no_grad():
+        mid = 0.5 * (a + c)
+        root = torch.sqrt(torch.clamp_min(mid * mid - det, K["lambda_floor"]))
+        lam = torch.maximum(mid + root, mid - root)
+        rad_f = torch.ceil(K["radius_sigma"] * torch.sqrt(lam))
+        rad_f = torch.clamp(rad_f, 0, 1e7)
+        B = K["tile"]
+        gx, gy = (W + B - 1) // B, (H + B - 1) // B
+        big = 1e8
+        pxc = torch.clamp(xy[:, 0].detach(), -big, big)
+        pyc = torch.clamp(xy[:, 1].detach(), -big, big)
+
+        def _tile(v, hi):
+            return torch.clamp(torch.trunc(v / B), 0, hi).to(torch.int32)
+
+        rmin = torch.stack([_tile(pxc - rad_f, gx), _tile(pyc - rad_f, gy)], dim=1)
+        rmax = torch.stack([_tile(pxc + rad_f + (B - 1), gx),
+                            _tile(pyc + rad_f + (B - 1), gy)], dim=1)
+        area = (rmax[:, 0] - rmin[:, 0]) * (rmax[:, 1] - rmin[:, 1])
+        visible = in_front & det_ok & (area > 0)
+        radii = torch.where(visible, rad_f.to(torch.int32), torch.zeros_like(area))
+        rmin = torch.where(visible[:, None], rmin, torch.zeros_like(rmin))
+        rmax = torch.where(visible[:, None], rmax, torch.zeros_like(rmax))
+
+    if colors_precomp is not None:
+        rgb = colors_precomp
+    else:
+        deg = int(settings.sh_degree)
+        campos = settings.campos.to(dt).reshape(-1)[:3]
+        dirs = means3D - campos[None, :]
+        dirs = dirs / torch.linalg.norm(dirs, dim=1, keepdim=True)
+        rgb = torch.clamp_min(eval_sh_color(deg, shs, dirs) + 0.5, 0.0)
+
+    return Projected(xy, conic, depth, rgb, opacities.reshape(-1), radii, rmin, rmax,
+                     torch.stack([a, b, c], dim=1))
+
+
+# --------------------------------------------------------------------------- #
+# per-tile compositing
+# --------------------------------------------------------------------------- #
+def composite(proj: Projected, settings: RasterSettings):
+    """Front-to-back alpha compositing per 16x16 tile (contract rows a5-a6).
+    Returns image[3,H,W], depth[1,H,W], opacity[1,H,W] (detached),
+    n_touched[N] int32, and `pairs`, the number of (tile, Gaussian) duplicates
+    the reference binning would emit."""
+    K = CONSTANTS
+    dt = proj.xy.dtype
+    H, W = int(settings.image_height), int(settings.image_width)
+    B = K["tile"]
+    gx, gy = (W + B - 1) // B, (H + B - 1) // B
+    bg = settings.bg.to(dt).reshape(3)
+    N = proj.xy.shape[0]
+
+    img_rows, dep_rows, opa_rows = [], [], []
+    n_touched = torch.zeros(N, dtype=torch.int64)
+    pairs = 0
+    vis_idx = torch.nonzero(proj.radii > 0).reshape(-1)
+    rmin, rmax = proj.rect_min[vis_idx], proj.rect_max[vis_idx]
+    depth_d = proj.depth.detach()[vis_idx]
+
+    for ty in range(gy):
+        row_img, row_dep, row_opa = [], [], []
+        in_row = (rmin[:, 1] <= ty) & (rmax[:, 1] > ty)
+        for tx in range(gx):
+            sel = in_row & (rmin[:, 0] <= tx) & (rmax[:, 0] > tx)
+            ids = vis_idx[sel]
+            pairs += int(ids.numel())
+            # stable sort by depth; ties keep ascending Gaussian index
+            order = torch.sort(depth_d[sel], stable=True).indices
+            ids = ids[order]
+            ys = torch.arange(ty * B, ty * B + B, dtype=dt)
+            xs = torch.arange(tx * B, tx * B + B, dtype=dt)
+            PY, PX = torch.meshgrid(ys, xs, indexing="ij")
+            PX, PY = PX.reshape(-1), PY.reshape(-1)          # [256]
+            if ids.numel() == 0:
+                C = bg[:, None].expand(3, B * B) + 0 * PX[None]
+                D = torch.zeros(B * B, dtype=dt)
+                O = torch.zeros(B * B, dtype=dt)
+            else:
+                xy = proj.xy[ids]
+                con = proj.conic[ids]
+                dx = xy[:, 0:1] - PX[None, :]
+                dy = xy[:, 1:2] - PY[None, :]
+                power = (-0.5 * (con[:, 0:1] * dx * dx + con[:, 2:3] * dy * dy)
+                         - con[:, 1:2] * dx * dy)
+                raw = proj.opacity[ids][:, None] * torch.exp(power)
+                alpha = raw + (torch.clamp_max(raw, K["alpha_max"]) - raw).detach()
+                valid = (power <= 0) & (alpha.detach() >= K["alpha_min"])
+                a = torch.where(valid, alpha, torch.zeros_like(alpha))
+                one_m = 1.0 - a
+                T_incl = torch.cumprod(one_m, dim=0)
+                T_excl = torch.cat([torch.ones(1, B * B, dtype=dt), T_incl[:-1]], dim=0)
+                include = valid & (T_incl.detach() >= K["t_stop"])
+                w = torch.where(include, a * T_excl, torch.zeros_like(a))
+                T_fin = torch.prod(torch.where(include, one_m, torch.ones_like(one_m)), dim=0)
+                C = proj.rgb[ids].t() @ w + T_fin[None, :] * bg[:, None]
+                D = proj.depth[ids] @ w
+                O = (1.0 - T_fin).detach()
+                touched = include & (T_incl.detach() > K["touch_t"])
+                inside = (PX < W) & (PY < H)
+                n_touched.index_add_(0, ids, (touched & inside[None, :]).sum(dim=1))
+            row_img.append(C.reshape(3, B, B))
+            row_dep.append(D.reshape(1, B, B))
+            row_opa.append(O.reshape(1, B, B))
+        img_rows.append(torch.cat(row_img, dim=2))
+        dep_rows.append(torch.cat(row_dep, dim=2))
+        opa_rows.append(torch.cat(row_opa, dim=2))
+    image = torch.cat(img_rows, dim=1)[:, :H, :W]
+    depth = torch.cat(dep_rows, dim=1)[:, :H, :W]
+    opacity = torch.cat(opa_rows, dim=1)[:, :H, :W]
+    return image, depth, opacity, n_touched.to(torch.int32), pairs
+
+
+def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+              cov3D_precomp, settings: RasterSettings, theta=None, rho=None):
+    """Oracle of `GaussianRasterizer.forward` (gaussian_renderer/__init__.py:151-168).
+    Returns (image, radii, depth, opacity, n_touched) plus an `info` dict."""
+    tau = None
+    if theta is not None or rho is not None:
+        z3 = torch.zeros(3, dtype=means3D.dtype)
+        tau = torch.cat([rho if rho is not None else z3,
+                         theta if theta is not None else z3])
+    proj = project(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                   cov3D_precomp, settings, tau)
+    image, depth, opacity, n_touched, pairs = composite(proj, settings)
+    info = dict(proj=proj, pairs=pairs, n_visible=int((proj.radii > 0).sum()))
+    return image, proj.radii, depth, opacity, n_touched, info
+
+
+def dist2_knn3(points: torch.Tensor) -> torch.Tensor:
+    """Oracle of simple_knn._C.distCUDA2 (gaussian_model.py:185-191): mean squared
+    distance to the 3 nearest other points (exact). O(P^2), chunked."""
+    P = points.shape[0]
+    out = torch.empty(P, dtype=points.dtype)
+    p64 = points.double()
+    for s in range(0, P, 2048):
+        q = p64[s:s + 2048]
+        d2 = ((q[:, None, :] - p64[None, :, :]) ** 2).sum(-1)
+        d2[torch.arange(q.shape[0]), torch.arange(s, s + q.shape[0])] = float("inf")
+        k = min(3, P - 1)
+        best = torch.topk(d2, k, dim=1, largest=False).values
+        out[s:s + 2048] = (best.sum(1) / 3.0).to(points.dtype)
+    return out

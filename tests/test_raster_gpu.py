@@ -1,0 +1,322 @@
+"""GPU parity tests: HIP rasteriser (through the C ABI + autograd binding) against the
+autograd oracle (small sizes) and the C++ host emulation (full BASELINE sizes).
+
+Tolerances (BASELINE.json north_star): forward image L1 <= 1e-4; backward gradients
+<= 1e-3 relative (norm-wise: the alpha>=1/255 and T<1e-4 cut-offs are discontinuous, so a
+handful of (pixel, splat) pairs may flip between two fp32 implementations).
+"""
+import pytest
+import torch
+
+from conftest import gpu_settings, oracle_settings, rel_err
+
+pytestmark = pytest.mark.gpu
+
+FWD_L1 = 1e-4
+BWD_REL = 1e-3
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _inputs(sc, deg=0, seed=1):
+    from monogs_amd import synthetic as S
+    m, s, r, o, sh = S.activated(sc)
+    if deg > 0:
+        g = torch.Generator().manual_seed(seed)
+        K = (deg + 1) ** 2
+        sh = torch.cat([sh, 0.3 * torch.randn(sh.shape[0], K - 1, 3, generator=g)], 1)
+    return m, s, r, o, sh
+
+
+def _run_gpu(sc, st, m, s, r, o, sh, col=None, cov=None, backward=True, loss_fn=None):
+    from monogs_amd import synthetic as S
+    from monogs_amd.rasterizer import GaussianRasterizer
+    dev = _dev()
+    req = lambda t: None if t is None else t.clone().to(dev).requires_grad_()
+    L = dict(m=req(m), s=req(s), r=req(r), o=req(o), sh=req(sh), col=req(col), cov=req(cov))
+    theta = torch.zeros(3, device=dev, requires_grad=True)
+    rho = torch.zeros(3, device=dev, requires_grad=True)
+    m2d = torch.zeros(m.shape[0], 3, device=dev, requires_grad=True)
+    out = GaussianRasterizer(st)(means3D=L["m"], means2D=m2d, shs=L["sh"], colors_precomp=L["col"],
+                                 opacities=L["o"], scales=L["s"], rotations=L["r"],
+                                 cov3D_precomp=L["cov"], theta=theta, rho=rho)
+    img, radii, dep, opa, nt = out
+    if backward:
+        loss = (loss_fn or (lambda i, d: S.synthetic_loss(i, d, sc)))(img, dep)
+        loss.backward()
+    torch.cuda.synchronize()
+    return out, L, theta, rho, m2d
+
+
+def _run_oracle(sc, st, m, s, r, o, sh, col=None, cov=None, loss_fn=None):
+    from monogs_amd import synthetic as S
+    from oracle import torch_raster as O
+    req = lambda t: None if t is None else t.clone().requires_grad_()
+    L = dict(m=req(m), s=req(s), r=req(r), o=req(o), sh=req(sh), col=req(col), cov=req(cov))
+    theta = torch.zeros(3, requires_grad=True)
+    rho = torch.zeros(3, requires_grad=True)
+    m2d = torch.zeros(m.shape[0], 3, requires_grad=True)
+    img, radii, dep, opa, nt, info = O.rasterize(L["m"], m2d, L["sh"], L["col"], L["o"], L["s"],
+                                                 L["r"], L["cov"], st, theta, rho)
+    loss = (loss_fn or (lambda i, d: S.synthetic_loss(i, d, sc)))(img, dep)
+    loss.backward()
+    return (img, radii, dep, opa, nt), L, theta, rho, m2d, info
+
+
+def _compare(gpu, ora, check_sr=True):
+    (gimg, gradii, gdep, gopa, gnt), GL, gth, grh, gm2d = gpu
+    (oimg, oradii, odep, oopa, ont), OL, oth, orh, om2d = ora[:5]
+    assert (gimg.cpu() - oimg).abs().mean().item() <= FWD_L1
+    assert (gdep.cpu() - odep).abs().mean().item() <= 5e-4
+    assert (gopa.cpu() - oopa).abs().mean().item() <= FWD_L1
+    assert (gradii.cpu() != oradii).float().mean().item() <= 1e-3
+    nt_bad = (gnt.cpu() != ont).float().sum().item()
+    assert nt_bad <= max(2, 0.01 * (ont > 0).sum().item()), nt_bad
+    assert rel_err(GL["m"].grad, OL["m"].grad) <= BWD_REL
+    assert rel_err(gm2d.grad, om2d.grad) <= BWD_REL
+    assert gm2d.grad[:, 2].abs().max().item() == 0.0
+    assert rel_err(GL["o"].grad, OL["o"].grad) <= BWD_REL
+    if GL["sh"] is not None:
+        assert rel_err(GL["sh"].grad, OL["sh"].grad) <= BWD_REL
+    if GL["col"] is not None:
+        assert rel_err(GL["col"].grad, OL["col"].grad) <= BWD_REL
+    if check_sr and GL["s"] is not None:
+        assert rel_err(GL["s"].grad, OL["s"].grad) <= BWD_REL
+        assert rel_err(GL["r"].grad, OL["r"].grad) <= BWD_REL
+    if GL["cov"] is not None:
+        assert rel_err(GL["cov"].grad, OL["cov"].grad) <= BWD_REL
+    tau_g = torch.cat([grh.grad, gth.grad])
+    tau_o = torch.cat([orh.grad, oth.grad])
+    assert rel_err(tau_g, tau_o) <= 2e-3
+
+
+def test_small_sh0(built):
+    from monogs_amd import synthetic as S
+    sc = S.make_scene(2000, 160, 120, seed=3)
+    inp = _inputs(sc)
+    bg = torch.tensor([0.1, 0.3, 0.2])
+    gpu = _run_gpu(sc, gpu_settings(sc.cam, bg, _dev()), *inp)
+    ora = _run_oracle(sc, oracle_settings(sc.cam, bg), *inp)
+    _compare(gpu, ora)
+
+
+def test_syn_a_config1(built):
+    """BASELINE config 1 shape: 5k Gaussians @160x120, one fwd+bwd."""
+    from monogs_amd import synthetic as S
+    sc = S.make_scene(5000, 160, 120, seed=0)
+    inp = _inputs(sc)
+    gpu = _run_gpu(sc, gpu_settings(sc.cam, sc.bg, _dev()), *inp)
+    ora = _run_oracle(sc, oracle_settings(sc.cam, sc.bg), *inp)
+    _compare(gpu, ora)
+
+
+def test_sh_degree3_and_campos(built):
+    from monogs_amd import synthetic as S
+    sc = S.make_scene(1500, 128, 96, seed=5)
+    inp = _inputs(sc, deg=3)
+    campos = torch.tensor([0.1, -0.2, -0.5])
+    bg = torch.tensor([0.0, 0.5, 1.0])
+    gpu = _run_gpu(sc, gpu_settings(sc.cam, bg, _dev(), deg=3, campos=campos), *inp)
+    ora = _run_oracle(sc, oracle_settings(sc.cam, bg, deg=3, campos=campos), *inp)
+    _compare(gpu, ora)
+
+
+def test_active_degree_below_stored(built):
+    """MonoGS stores K coefficients but may render with a lower active degree."""
+    from monogs_amd import synthetic as S
+    sc = S.make_scene(800, 96, 64, seed=6)
+    inp = _inputs(sc, deg=2)
+    campos = torch.tensor([0.0, 0.1, -0.3])
+    gpu = _run_gpu(sc, gpu_settings(sc.cam, sc.bg, _dev(), deg=1, campos=campos), *inp)
+    ora = _run_oracle(sc, oracle_settings(sc.cam, sc.bg, deg=1, campos=campos), *inp)
+    _compare(gpu, ora)
+
+
+def test_precomputed_cov_and_colors(built):
+    from monogs_amd import synthetic as S
+    from oracle import torch_raster as O
+    sc = S.make_scene(1200, 112, 80, seed=7)
+    m, s, r, o, sh = _inputs(sc)
+    Sig = O.cov3d_from_scale_rot(s, r, 1.0)
+    cov6 = torch.stack([Sig[:, 0, 0], Sig[:, 0, 1], Sig[:, 0, 2], Sig[:, 1, 1], Sig[:, 1, 2],
+                        Sig[:, 2, 2]], 1).contiguous()
+    col = torch.rand(m.shape[0], 3, generator=torch.Generator().manual_seed(2))
+    gpu = _run_gpu(sc, gpu_settings(sc.cam, sc.bg, _dev()), m, None, None, o, None, col, cov6)
+    ora = _run_oracle(sc, oracle_settings(sc.cam, sc.bg), m, None, None, o, None, col, cov6)
+    _compare(gpu, ora)
+
+
+def test_odd_image_size_and_moved_camera(built):
+    """W,H not multiples of 16 and a non-identity pose (rotation + translation)."""
+    from monogs_amd import synthetic as S
+    from oracle import torch_raster as O
+    sc = S.make_scene(1500, 150, 101, seed=8)
+    T = O.se3_exp(torch.tensor([0.05, -0.03, 0.1, 0.02, -0.04, 0.03]))
+    cam = S.make_camera(150, 101, T)
+    sc = sc._replace(cam=cam)
+    inp = _inputs(sc)
+    gpu = _run_gpu(sc, gpu_settings(cam, sc.bg, _dev()), *inp)
+    ora = _run_oracle(sc, oracle_settings(cam, sc.bg), *inp)
+    _compare(gpu, ora)
+
+
+def test_scale_modifier_and_isotropic_broadcast(built):
+    """render() repeats [N,1] isotropic scales to [N,3] (gaussian_renderer/__init__.py:92-93)."""
+    from monogs_amd import synthetic as S
+    sc = S.make_scene(1000, 96, 80, seed=9)
+    m, s, r, o, sh = _inputs(sc)
+    s = s[:, :1].repeat(1, 3).contiguous()
+    gpu = _run_gpu(sc, gpu_settings(sc.cam, sc.bg, _dev(), scale_modifier=0.7), m, s, r, o, sh)
+    ora = _run_oracle(sc, oracle_settings(sc.cam, sc.bg, scale_modifier=0.7), m, s, r, o, sh)
+    _compare(gpu, ora)
+
+
+def test_everything_culled_and_single_gaussian(built):
+    from monogs_amd import synthetic as S
+    dev = _dev()
+    sc = S.make_scene(64, 64, 48, seed=1)
+    m, s, r, o, sh = _inputs(sc)
+    behind = m.clone()
+    behind[:, 2] = -1.0
+    (img, radii, dep, opa, nt), L, th, rh, m2d = _run_gpu(
+        sc, gpu_settings(sc.cam, torch.tensor([0.2, 0.4, 0.6]), dev), behind, s, r, o, sh)
+    assert (radii == 0).all() and (nt == 0).all()
+    assert torch.allclose(img.cpu(), torch.tensor([0.2, 0.4, 0.6])[:, None, None].expand(3, 48, 64))
+    assert (dep == 0).all() and (opa == 0).all()
+    assert L["m"].grad.abs().max().item() == 0 and rh.grad.abs().max().item() == 0
+    one = lambda t: t[:1].contiguous()
+    gpu = _run_gpu(sc, gpu_settings(sc.cam, sc.bg, dev), one(m), one(s) * 4, one(r), one(o), one(sh))
+    ora = _run_oracle(sc, oracle_settings(sc.cam, sc.bg), one(m), one(s) * 4, one(r), one(o), one(sh))
+    _compare(gpu, ora)
+
+
+def test_backward_is_reentrant(built):
+    """slam_frontend.py:654-666 calls backward repeat_dim times with retain_graph=True."""
+    from monogs_amd import synthetic as S
+    from monogs_amd.rasterizer import GaussianRasterizer
+    dev = _dev()
+    sc = S.make_scene(1500, 128, 96, seed=4)
+    m, s, r, o, sh = [t.to(dev).requires_grad_() for t in _inputs(sc)]
+    theta = torch.zeros(3, device=dev, requires_grad=True)
+    rho = torch.zeros(3, device=dev, requires_grad=True)
+    m2d = torch.zeros(1500, 3, device=dev, requires_grad=True)
+    img, radii, dep, opa, nt = GaussianRasterizer(gpu_settings(sc.cam, sc.bg, dev))(
+        means3D=m, means2D=m2d, shs=sh, opacities=o, scales=s, rotations=r, theta=theta, rho=rho)
+    loss = S.synthetic_loss(img, dep, sc)
+    loss.backward(retain_graph=True)
+    g1, t1 = m.grad.clone(), theta.grad.clone()
+    m.grad = None
+    theta.grad = None
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(g1, m.grad) and torch.equal(t1, theta.grad)
+
+
+def test_capacity_retry_gives_identical_result(built):
+    from monogs_amd import rasterizer as R
+    from monogs_amd import synthetic as S
+    dev = _dev()
+    sc = S.make_scene(3000, 160, 120, seed=2)
+    inp = _inputs(sc)
+    st = gpu_settings(sc.cam, sc.bg, dev)
+    a = _run_gpu(sc, st, *inp)
+    pairs = R.last_stats["pairs"]
+    R._capacity_hint[dev.index] = 1024          # far too small -> stage 2 must be re-run
+    b = _run_gpu(sc, st, *inp)
+    assert R.last_stats["retried"] and R.last_stats["pairs"] == pairs
+    assert torch.equal(a[0][0], b[0][0]) and torch.equal(a[0][4], b[0][4])
+    assert torch.equal(a[1]["m"].grad, b[1]["m"].grad)
+
+
+def test_pair_count_matches_exact_culling_emulation(built):
+    from monogs_amd import rasterizer as R
+    from monogs_amd import synthetic as S
+    from oracle.host_emul import HostEmul
+    sc = S.make_scene(5000, 160, 120, seed=0)
+    inp = _inputs(sc)
+    _run_gpu(sc, gpu_settings(sc.cam, sc.bg, _dev()), *inp, backward=False)
+    em = HostEmul()
+    m, s, r, o, sh = inp
+    em.forward(oracle_settings(sc.cam, sc.bg), m, sh, None, o, s, r, None, exact_cull=True)
+    assert abs(R.last_stats["pairs"] - em.pairs) <= max(2, em.pairs // 1000)
+
+
+@pytest.mark.parametrize("N,backward", [(100_000, False), (300_000, True)])
+def test_full_size_against_host_emulation(built, N, backward):
+    """BASELINE configs 2 and 3: 640x480, 100k forward / 300k forward+backward, checked
+    against the multi-threaded C++ host emulation (itself pinned to the autograd oracle
+    by the CPU tests)."""
+    from monogs_amd import synthetic as S
+    from oracle.host_emul import HostEmul
+    sc = S.make_scene(N, 640, 480, seed=0)
+    inp = _inputs(sc)
+    m, s, r, o, sh = inp
+    gpu = _run_gpu(sc, gpu_settings(sc.cam, sc.bg, _dev()), *inp, backward=backward)
+    (img, radii, dep, opa, nt), L, th, rh, m2d = gpu
+    em = HostEmul()
+    eimg, eradii, edep, eopa, ent = em.forward(oracle_settings(sc.cam, sc.bg), m, sh, None, o, s,
+                                               r, None, exact_cull=False)
+    assert (img.cpu() - eimg).abs().mean().item() <= FWD_L1
+    assert (dep.cpu() - edep).abs().mean().item() <= 5e-4
+    assert (opa.cpu() - eopa).abs().mean().item() <= FWD_L1
+    assert (radii.cpu() != eradii).float().mean().item() <= 1e-4
+    assert (nt.cpu() != ent).float().mean().item() <= 1e-3
+    if backward:
+        gi = img.detach().cpu().requires_grad_()
+        gd = dep.detach().cpu().requires_grad_()
+        S.synthetic_loss(gi, gd, sc).backward()
+        out = em.backward(gi.grad, gd.grad)
+        assert rel_err(L["m"].grad, out["means3D"]) <= BWD_REL
+        assert rel_err(m2d.grad, out["means2D"]) <= BWD_REL
+        assert rel_err(L["sh"].grad, out["colors"]) <= BWD_REL
+        assert rel_err(L["o"].grad.reshape(-1), out["opacities"]) <= BWD_REL
+        assert rel_err(L["s"].grad, out["scales"]) <= BWD_REL
+        assert rel_err(L["r"].grad, out["rotations"]) <= BWD_REL
+        assert rel_err(torch.cat([rh.grad, th.grad]), out["tau"]) <= 2e-3
+
+
+def test_no_gradient_through_opacity_output(built):
+    """The extension's backward receives only grad_out_color and grad_out_depth: a loss on
+    the `opacity` output alone produces zero gradients."""
+    from monogs_amd import synthetic as S
+    sc = S.make_scene(500, 64, 48, seed=11)
+    inp = _inputs(sc)
+    from monogs_amd.rasterizer import GaussianRasterizer
+    dev = _dev()
+    m, s, r, o, sh = [t.to(dev).requires_grad_() for t in inp]
+    img, radii, dep, opa, nt = GaussianRasterizer(gpu_settings(sc.cam, sc.bg, dev))(
+        means3D=m, means2D=torch.zeros(500, 3, device=dev, requires_grad=True), shs=sh,
+        opacities=o, scales=s, rotations=r)
+    (opa.sum() + 0 * img.sum()).backward()
+    assert m.grad.abs().max().item() == 0 and o.grad.abs().max().item() == 0
+
+
+def test_argument_validation(built):
+    from monogs_amd import synthetic as S
+    from monogs_amd.rasterizer import GaussianRasterizer
+    dev = _dev()
+    sc = S.make_scene(16, 32, 32)
+    m, s, r, o, sh = [t.to(dev) for t in _inputs(sc)]
+    ras = GaussianRasterizer(gpu_settings(sc.cam, sc.bg, dev))
+    z = torch.zeros(16, 3, device=dev)
+    with pytest.raises(Exception):
+        ras(means3D=m, means2D=z, opacities=o, shs=sh, colors_precomp=z, scales=s, rotations=r)
+    with pytest.raises(Exception):
+        ras(means3D=m, means2D=z, opacities=o, shs=sh)
+    with pytest.raises(RuntimeError):
+        ras(means3D=m.cpu(), means2D=z.cpu(), opacities=o.cpu(), shs=sh.cpu(), scales=s.cpu(),
+            rotations=r.cpu())
+
+
+def test_knn_dist2(built):
+    from monogs_amd.knn import distCUDA2
+    from oracle import torch_raster as O
+    g = torch.Generator().manual_seed(0)
+    for P in (4, 257, 4800):
+        pts = torch.rand(P, 3, generator=g) * torch.tensor([4.0, 3.0, 6.0])
+        got = distCUDA2(pts.to(_dev())).cpu()
+        want = O.dist2_knn3(pts)
+        assert torch.allclose(got, want, rtol=1e-4, atol=1e-7), P
