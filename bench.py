@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: rasteriser forward+backward (incl. pose Jacobian) on the
+SYN-C workload of BASELINE.md §4 (640x480, 300k Gaussians, SH degree 0).
+
+    python bench.py --gpus N --steps K --warmup W
+
+N = 1: one view per step through the autograd binding (what MonoGS's render() +
+loss.backward() exercises).  N > 1 (launched by torch.distributed.run, one rank per
+GPU): keyframe-parallel mapping - Gaussians replicated, one view per rank,
+one RCCL all-reduce(sum) of the flat Gaussian-gradient buffer per step; value = views/s
+over all ranks ("weak" scaling: per-GPU work fixed).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline`
+(dominant kernel, HIP-event timed inside the library on the launch stream) and
+`cpu_baseline` (C++ host emulation on the host cores, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--gaussians", type=int, default=300_000)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=20)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (HIP kernels only; no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import __graft_entry__ as entry
+    if not os.path.exists(entry.LIB):
+        entry.build()
+    from monogs_amd import _cabi, rasterizer as R, synthetic as S
+    from monogs_amd.parallel import FlatGradBucket, view_pose
+
+    N, W, H = args.gaussians, args.width, args.height
+    sc = S.make_scene(N, W, H, seed=0)
+    # every rank renders its own view of the same (replicated) map
+    cam = S.make_camera(W, H, view_pose(rank)) if distributed else sc.cam
+    m, s, r, o, sh = S.activated(sc)
+    params = [t.to(dev).requires_grad_() for t in (m, s, r, o, sh)]
+    theta = torch.zeros(3, device=dev, requires_grad=True)
+    rho = torch.zeros(3, device=dev, requires_grad=True)
+    bg = sc.bg.to(dev)
+    st = R.GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, bg, 1.0,
+                                         cam.viewmatrix.to(dev), cam.projmatrix.to(dev),
+                                         cam.projmatrix_raw.to(dev), 0, cam.viewmatrix.to(dev),
+                                         False, False)
+    ras = R.GaussianRasterizer(st)
+    gt_img, gt_dep = sc.gt_image.to(dev), sc.gt_depth.to(dev)
+    bucket = FlatGradBucket(params) if distributed else None
+
+    def step():
+        for p in params:
+            p.grad = None
+        theta.grad = None
+        rho.grad = None
+        m2d = torch.zeros(N, 3, device=dev, requires_grad=True)
+        img, radii, dep, opa, nt = ras(means3D=params[0], means2D=m2d, shs=params[4],
+                                       opacities=params[3], scales=params[1],
+                                       rotations=params[2], theta=theta, rho=rho)
+        loss = (img - gt_img).abs().mean() + 0.05 * (dep - gt_dep).abs().mean()
+        loss.backward()
+        if bucket is not None:
+            bucket.all_reduce(m2d.grad, radii)
+        return loss
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if distributed:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * args.steps / dt          # views (frames) per second, whole job
+    D = int(R.last_stats["pairs"])
+
+    # ---- per-kernel timing (separate pass; events slow the stream down slightly) ----
+    roofline = None
+    kernels = {}
+    if rank == 0 and args.profile_steps > 0:
+        torch.cuda.synchronize()
+        _cabi.profile_enable(True)
+        for _ in range(args.profile_steps):
+            step()
+        torch.cuda.synchronize()
+        prof = _cabi.profile_read()
+        _cabi.profile_enable(False)
+        kernels = {k: round(v[0] / v[1] * 1e3, 2) for k, v in prof.items()}  # us / launch
+        # algorithmic bytes per launch of each kernel (SURVEY §8d split)
+        HW = W * H
+        alg = {
+            "preprocess": 56 * N + 48 * N + 8 * N,
+            "bin_count": 32 * N + 4 * N,
+            "bin_emit": 32 * N + 12 * D,
+            "tile_sort": 24 * D,
+            "blend_fwd": 52 * D + 28 * HW,
+            "blend_bwd": 52 * D + 40 * D + 24 * HW,
+            "preprocess_bwd": 56 * N + 40 * D + 48 * N + 68 * N,
+        }
+        dom = max((k for k in kernels if k in alg), key=lambda k: kernels[k])
+        achieved = alg[dom] / (kernels[dom] * 1e-6) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0,
+                    "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
+                    "algorithmic_bytes": alg[dom], "avg_us": kernels[dom]}
+
+    # ---- CPU baseline: the C++ host emulation on the host cores (rank 0, N = 1) ----
+    cpu_baseline = None
+    if rank == 0 and not distributed and not args.no_cpu_baseline:
+        from oracle import torch_raster as O
+        from oracle.host_emul import HostEmul
+        st_c = O.RasterSettings(H, W, cam.tanfovx, cam.tanfovy, sc.bg, 1.0, cam.viewmatrix,
+                                cam.projmatrix, cam.projmatrix_raw, 0, cam.viewmatrix, False, False)
+        em = HostEmul()
+        gi = torch.sign(torch.randn(3, H, W)) / (3 * H * W)
+        gd = 0.05 * torch.sign(torch.randn(1, H, W)) / (H * W)
+        reps, t_cpu = 0, 0.0
+        while t_cpu < 10.0 and reps < 50:
+            t1 = time.perf_counter()
+            em.forward(st_c, m, sh, None, o, s, r, None, exact_cull=False)
+            em.backward(gi, gd)
+            t_cpu += time.perf_counter() - t1
+            reps += 1
+        cpu_baseline = {"value": round(reps / t_cpu, 3), "unit": "frames/s",
+                        "cores": os.cpu_count(), "kind": "port",
+                        "sample": f"{reps} fwd+bwd of the same SYN-C workload "
+                                  f"({N} Gaussians @ {W}x{H}), OpenMP C++ host emulation "
+                                  "(oracle/host_emul.cpp)"}
+
+    if rank == 0:
+        out = {
+            "metric": "rasteriser fwd+bwd fps @640x480/300k Gaussians",
+            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"SYN-C: {N} Gaussians @ {W}x{H}, SH degree 0, fwd+bwd incl. "
+                                   "pose Jacobian through the autograd binding",
+                       "pairs_D": D, "views_per_step": world,
+                       "parallelism": f"keyframe-parallel x{world}" if distributed else "single view"},
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels_us": kernels,
+        }
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -130,7 +130,7 @@ int32_t mgs_raster_workspace_query(const mgs_raster_shape* shape, mgs_workspace_
 
 /* Forward, stage 1: projection + EWA splat + pair counting + tile scan.
  * Needs `geom` only.  On return (stream order) counters[0] in geom holds D, the
- * number of (tile, Gaussian) pairs; radii is final; n_touched is zeroed. */
+ * number of (tile, Gaussian) pairs; radii is final. */
 int32_t mgs_raster_forward_project(const mgs_forward_args* args, void* stream);
 
 /* Forward, stage 2: pair emission, per-tile depth sort, front-to-back blend.
@@ -145,6 +145,14 @@ int32_t mgs_raster_backward(const mgs_backward_args* args, void* stream);
 uint64_t mgs_knn_scratch_bytes(int32_t num_points);
 int32_t mgs_knn_dist2(const float* points, int32_t num_points, float* out, void* scratch,
                       void* stream);
+
+/* Per-kernel timing (diagnostics; used by bench.py for the roofline line).  While
+ * enabled every kernel launch is bracketed by hipEvents on the launch stream.
+ * mgs_profile_read waits for the recorded events, aggregates them by kernel name into
+ * names[k*32 .. k*32+31] / total_ms[k] / launches[k], clears the log and returns the
+ * number of distinct names (<= max_entries), or a negative status. */
+int32_t mgs_profile_enable(int32_t on);
+int32_t mgs_profile_read(int32_t max_entries, char* names, float* total_ms, int32_t* launches);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,7 @@ ABI_VERSION = 1
 EXPORTS = (
     "mgs_abi_version", "mgs_status_string", "mgs_raster_workspace_query",
     "mgs_raster_forward_project", "mgs_raster_forward_blend", "mgs_raster_backward",
-    "mgs_knn_scratch_bytes", "mgs_knn_dist2",
+    "mgs_knn_scratch_bytes", "mgs_knn_dist2", "mgs_profile_enable", "mgs_profile_read",
 )
 
 _fp = C.c_void_p  # device pointers travel as plain addresses
@@ -86,6 +86,11 @@ def lib():
     L.mgs_knn_scratch_bytes.argtypes = [C.c_int32]
     L.mgs_knn_dist2.restype = C.c_int32
     L.mgs_knn_dist2.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mgs_profile_enable.restype = C.c_int32
+    L.mgs_profile_enable.argtypes = [C.c_int32]
+    L.mgs_profile_read.restype = C.c_int32
+    L.mgs_profile_read.argtypes = [C.c_int32, C.c_char_p, C.POINTER(C.c_float),
+                                   C.POINTER(C.c_int32)]
     if L.mgs_abi_version() != ABI_VERSION:
         raise NativeLibraryError(
             f"ABI mismatch: library {L.mgs_abi_version()} vs binding {ABI_VERSION}")
@@ -103,4 +108,23 @@ def workspace_sizes(shape: RasterShape) -> WorkspaceSizes:
     out = WorkspaceSizes()
     check(lib().mgs_raster_workspace_query(C.byref(shape), C.byref(out)),
           "mgs_raster_workspace_query")
+    return out
+
+
+def profile_enable(on: bool) -> None:
+    check(lib().mgs_profile_enable(1 if on else 0), "mgs_profile_enable")
+
+
+def profile_read(max_entries: int = 64) -> dict:
+    """{kernel name: (total_ms, launches)} since the last read (synchronises)."""
+    names = C.create_string_buffer(32 * max_entries)
+    ms = (C.c_float * max_entries)()
+    cnt = (C.c_int32 * max_entries)()
+    n = lib().mgs_profile_read(max_entries, names, ms, cnt)
+    if n < 0:
+        check(n, "mgs_profile_read")
+    out = {}
+    for k in range(n):
+        nm = names.raw[32 * k:32 * k + 32].split(b"\0", 1)[0].decode()
+        out[nm] = (float(ms[k]), int(cnt[k]))
     return out

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/monogs_raster.h"
+#include "launch.h"
 
 namespace mgs {
 
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn(const float* __restrict__ pts
 }
 
 int launch_knn(const float* pts, int n, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(k_knn, dim3((n + kKnnBlock - 1) / kKnnBlock), dim3(kKnnBlock), 0, st, pts, n, out);
+  launch("knn", k_knn, dim3((n + kKnnBlock - 1) / kKnnBlock), dim3(kKnnBlock), st, pts, n, out);
   return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
 }
 

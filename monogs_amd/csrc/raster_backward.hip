@@ -12,6 +12,7 @@
 // Replaces rasterize_gaussians_backward of the reference's CUDA extension (its
 // autograd.Function is invoked through gaussian_renderer/__init__.py:151-168; gradient
 // sinks: gaussian_model.py:252-285,693-697, slam_frontend.py:365-378,606-611).
+#include "launch.h"
 #include "raster_kernels.h"
 
 namespace mgs {
@@ -311,13 +312,13 @@ __global__ __launch_bounds__(384) void k_tau_reduce(KB B, int nblk) {
 // ---------------------------------------------------------------------------------
 int launch_backward(const KP& P, const KB& B, hipStream_t st) {
   const int nscan = (P.N + kScanBlock - 1) / kScanBlock;
-  hipLaunchKernelGGL(k_scan_reduce, dim3(nscan), dim3(256), 0, st, P, B);
-  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, B, nscan);
-  hipLaunchKernelGGL(k_scan_write, dim3(nscan), dim3(256), 0, st, P, B);
-  hipLaunchKernelGGL(k_blend_bwd, dim3(P.T), dim3(256), 0, st, P, B);
+  launch("scan_reduce", k_scan_reduce, dim3(nscan), dim3(256), st, P, B);
+  launch("scan_sums", k_scan_sums, dim3(1), dim3(1024), st, B, nscan);
+  launch("scan_write", k_scan_write, dim3(nscan), dim3(256), st, P, B);
+  launch("blend_bwd", k_blend_bwd, dim3(P.T), dim3(256), st, P, B);
   const int npre = (P.N + kPreBlock - 1) / kPreBlock;
-  hipLaunchKernelGGL(k_preprocess_bwd, dim3(npre), dim3(kPreBlock), 0, st, P, B);
-  hipLaunchKernelGGL(k_tau_reduce, dim3(1), dim3(384), 0, st, B, npre);
+  launch("preprocess_bwd", k_preprocess_bwd, dim3(npre), dim3(kPreBlock), st, P, B);
+  launch("tau_reduce", k_tau_reduce, dim3(1), dim3(384), st, B, npre);
   return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
 }
 

@@ -1,5 +1,25 @@
 // extern "C" entry points declared in include/monogs_raster.h.
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "launch.h"
 #include "raster_kernels.h"
+
+namespace mgs {
+namespace {
+struct ProfRec { const char* name; hipEvent_t a, b; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+std::mutex g_prof_mu;
+}  // namespace
+bool profile_on() { return g_prof_on; }
+void profile_push(const char* name, hipEvent_t a, hipEvent_t b) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof.push_back({name, a, b});
+}
+}  // namespace mgs
 
 namespace mgs {
 int launch_forward_project(const KP& P, hipStream_t st);
@@ -128,6 +148,41 @@ int32_t mgs_raster_backward(const mgs_backward_args* args, void* stream) {
   B.sketch_mode = 0; B.sketch_dim = 0; B.stack_dim = 0; B.sketch_idx = nullptr;
   B.g_sketch = nullptr; B.pix_jac = nullptr; B.splat_jac = nullptr;
   return launch_backward(P, B, (hipStream_t)stream);
+}
+
+int32_t mgs_profile_enable(int32_t on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on = on != 0;
+  return MGS_OK;
+}
+
+int32_t mgs_profile_read(int32_t max_entries, char* names, float* total_ms, int32_t* launches) {
+  if (max_entries < 0 || (max_entries > 0 && (!names || !total_ms || !launches)))
+    return MGS_ERR_BAD_ARGUMENT;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  int n = 0;
+  for (ProfRec& r : g_prof) {
+    (void)hipEventSynchronize(r.b);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, r.a, r.b);
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+    int k = 0;
+    for (; k < n; k++)
+      if (strncmp(names + 32 * k, r.name, 31) == 0) break;
+    if (k == n) {
+      if (n >= max_entries) continue;
+      strncpy(names + 32 * k, r.name, 31);
+      names[32 * k + 31] = 0;
+      total_ms[k] = 0.f;
+      launches[k] = 0;
+      n++;
+    }
+    total_ms[k] += ms;
+    launches[k] += 1;
+  }
+  g_prof.clear();
+  return n;
 }
 
 uint64_t mgs_knn_scratch_bytes(int32_t num_points) { (void)num_points; return 256; }

@@ -10,6 +10,7 @@
 //
 // Replaces rasterize_gaussians (forward) of the reference's CUDA extension, called at
 // /root/reference gaussian_splatting/gaussian_renderer/__init__.py:151-168.
+#include "launch.h"
 #include "raster_kernels.h"
 
 namespace mgs {
@@ -58,7 +59,6 @@ __global__ __launch_bounds__(kPreBlock) void k_preprocess(KP P) {
   dst[1] = make_float4(rec.ca, rec.cb, rec.cc, __int_as_float(rec.radius));
   dst[2] = make_float4(rec.r, rec.g, rec.b, __uint_as_float(rec.flags));
   P.radii[idx] = rec.radius;
-  P.n_touched[idx] = 0;
 }
 
 // ---------------------------------------------------------------------------------
@@ -259,19 +259,20 @@ static inline int check_launch() {
 
 int launch_forward_project(const KP& P, hipStream_t st) {
   const int nblk = (P.N + kPreBlock - 1) / kPreBlock;
-  hipLaunchKernelGGL(k_preprocess, dim3(nblk), dim3(kPreBlock), 0, st, P);
-  hipLaunchKernelGGL(k_bin, dim3((P.N + 255) / 256), dim3(256), 0, st, P, 0);
-  hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, P);
+  launch("preprocess", k_preprocess, dim3(nblk), dim3(kPreBlock), st, P);
+  launch("bin_count", k_bin, dim3((P.N + 255) / 256), dim3(256), st, P, 0);
+  launch("tile_scan", k_tile_scan, dim3(1), dim3(1024), st, P);
   return check_launch();
 }
 
 int launch_forward_blend(const KP& P, hipStream_t st) {
   // cursors restart at 0 on every call so a retry with a larger capacity is valid
-  if (hipMemsetAsync(P.tile_cursor, 0, sizeof(int) * (size_t)P.T, st) != hipSuccess)
+  if (hipMemsetAsync(P.tile_cursor, 0, sizeof(int) * (size_t)P.T, st) != hipSuccess ||
+      hipMemsetAsync(P.n_touched, 0, sizeof(int) * (size_t)P.N, st) != hipSuccess)
     return MGS_ERR_LAUNCH;
-  hipLaunchKernelGGL(k_bin, dim3((P.N + 255) / 256), dim3(256), 0, st, P, 1);
-  hipLaunchKernelGGL(k_tile_sort, dim3(P.T), dim3(256), 0, st, P);
-  hipLaunchKernelGGL(k_blend_fwd, dim3(P.T), dim3(256), 0, st, P);
+  launch("bin_emit", k_bin, dim3((P.N + 255) / 256), dim3(256), st, P, 1);
+  launch("tile_sort", k_tile_sort, dim3(P.T), dim3(256), st, P);
+  launch("blend_fwd", k_blend_fwd, dim3(P.T), dim3(256), st, P);
   return check_launch();
 }
 

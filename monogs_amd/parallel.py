@@ -1,0 +1,69 @@
+"""Keyframe-parallel mapping over one process per GPU.
+
+The reference has no distributed code (one GPU, `slam.py:109-117`); its mapping iteration
+is a sum of independent per-view losses over the keyframe window followed by one
+backward (`utils/slam_backend.py:183-247`).  That sum shards by view: Gaussians are
+replicated, view i of the window goes to rank i, and the only exchange step is ONE
+all-reduce(sum) over RCCL/xGMI of a flat fp32 buffer holding the Gaussian parameter
+gradients (xyz 3 + f_dc 3K + opacity 1 + scale 3 + rot 4) plus the two densification
+statistics of `gaussian_model.py:693-697` (||means2D.grad[:, :2]|| and the visibility
+count), followed by an all-reduce(max) of the radii (`max_radii2D`, slam_backend.py:292-296).
+Per-view parameters (pose deltas, exposure) stay on the owning rank.
+"""
+from __future__ import annotations
+
+import math
+from typing import Sequence
+
+import torch
+import torch.distributed as dist
+
+from .pose import SE3_exp
+
+
+def view_pose(i: int) -> torch.Tensor:
+    """Deterministic T_w2c of synthetic keyframe i: a small orbit around the first view."""
+    if i == 0:
+        return torch.eye(4)
+    a = 2.0 * math.pi * i / 8.0
+    tau = torch.tensor([0.06 * math.cos(a), 0.04 * math.sin(a), 0.02 * (i % 3 - 1),
+                        0.010 * math.sin(a), 0.012 * math.cos(a), 0.004 * i])
+    return SE3_exp(tau)
+
+
+class FlatGradBucket:
+    """One contiguous fp32 buffer = [param grads..., grad-norm stat, visibility stat]; a
+    single collective per iteration (xGMI is point-to-point: one large message per step
+    beats several small ones)."""
+
+    def __init__(self, params: Sequence[torch.Tensor]):
+        self.params = list(params)
+        self.N = int(self.params[0].shape[0])
+        dev = self.params[0].device
+        self.sizes = [p.numel() for p in self.params] + [self.N, self.N]
+        self.flat = torch.empty(sum(self.sizes), dtype=torch.float32, device=dev)
+        self.radii = torch.empty(self.N, dtype=torch.int32, device=dev)
+
+    def pack(self, means2D_grad: torch.Tensor, radii: torch.Tensor) -> None:
+        parts = [p.grad.reshape(-1) for p in self.params]
+        parts.append(torch.linalg.norm(means2D_grad[:, :2], dim=-1))
+        parts.append((radii > 0).to(torch.float32))
+        torch.cat(parts, out=self.flat)
+        self.radii.copy_(radii)
+
+    def unpack(self):
+        """Reduced gradients as views into the flat buffer + (grad_norm_sum, denom, max_radii)."""
+        out, off = [], 0
+        for p, n in zip(self.params, self.sizes):
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+        stat = self.flat[off:off + self.N]
+        denom = self.flat[off + self.N:off + 2 * self.N]
+        return stat, denom, self.radii
+
+    def all_reduce(self, means2D_grad: torch.Tensor, radii: torch.Tensor, group=None):
+        self.pack(means2D_grad, radii)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(self.radii, op=dist.ReduceOp.MAX, group=group)
+        return self.unpack()
