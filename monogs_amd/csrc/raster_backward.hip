@@ -45,6 +45,78 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
   return v;
 }
 
+// Ten wave64 sums at once, written directly as v_add_f32_dpp (the compiler otherwise
+// SLP-packs the adds into v_pk_add_f32, which cannot carry a DPP modifier, and emits
+// v_mov_dpp + v_mov + v_pk_add: 150 instructions instead of 60).  Each DPP step runs over
+// the ten registers in turn, so a register is re-read nine instructions after it was
+// written (>= the 2 wait states a DPP read needs); the leading s_nop covers the first.
+// Totals land in lane 63.
+__device__ __forceinline__ void wave_sum10_to_lane63(float (&r)[10]) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %9, %9, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %6, %6, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %7, %7, %7 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %9, %9, %9 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %4, %4 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %5, %5, %5 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %6, %6, %6 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %7, %7, %7 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %8, %8, %8 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %9, %9, %9 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %9, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_add_f32_dpp %5, %5, %5 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_add_f32_dpp %6, %6, %6 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_add_f32_dpp %7, %7, %7 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_add_f32_dpp %8, %8, %8 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_add_f32_dpp %9, %9, %9 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %4, %4 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "v_add_f32_dpp %5, %5, %5 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "v_add_f32_dpp %6, %6, %6 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "v_add_f32_dpp %7, %7, %7 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "v_add_f32_dpp %8, %8, %8 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "v_add_f32_dpp %9, %9, %9 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]));
+}
+
 // ---------------------------------------------------------------------------------
 // pair_base = exclusive scan of pair_count (N elements), three small launches.
 __global__ __launch_bounds__(256) void k_scan_reduce(KP P, KB B) {
@@ -110,53 +182,84 @@ __global__ __launch_bounds__(256) void k_scan_write(KP P, KB B) {
 }
 
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_blend_bwd(KP P, KB B) {
-  __shared__ float4 s_r0[256], s_r1[256], s_r2[256];
-  __shared__ int s_slot[256];
-  __shared__ float s_acc[256 * 10];
+// Back-to-front replay, one workgroup (2 waves) per 16x16 tile, TWO pixels per lane
+// (rows y and y+8 of the same column, so dx is shared and the fp32 work of the pair
+// packs into v_pk_* instructions).
+//
+// Per splat and pixel the replay produces a weight W = dL/dG * G and a blend weight
+// w = alpha * T; every screen-space gradient of the splat is a pixel sum of W or w times
+// a monomial of (dx, dy) or the pixel's upstream gradient:
+//   S1 = sum W, Sx = sum W dx, Sy = sum W dy, Sxx, Sxy, Syy      (mean2D, conic, opacity)
+//   Rr, Rg, Rb = sum w * dL/dC_ch,  Rd = sum w * dL/dD            (colour, depth)
+// The lane first adds its two pixels, the 10 sums are reduced over the wave with DPP,
+// written by lane 63 to the wave's own LDS partial (no atomics, fixed order =>
+// deterministic) and combined / converted by the thread that staged the splat, which
+// stores the pair's 40-B record once at its slot.
+//
+// A splat that does not contribute to a pixel is replayed as a transparent layer
+// (alpha = 0): the recurrences stay branch-free and the "colour of the previously
+// visited splat" is wave-uniform.
+constexpr int kBwdBatch = 128;
+constexpr int kBwdThreads = 128;
+constexpr float kLog2eB = 1.4426950408889634f;
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(kBwdThreads) void k_blend_bwd(KP P, KB B) {
+  __shared__ float4 s_r0[kBwdBatch], s_r1[kBwdBatch], s_r2[kBwdBatch];
+  __shared__ float4 s_part[2][kBwdBatch][3];
   __shared__ int s_maxlast;
-  const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tx = tile % P.grid_x, ty = tile / P.grid_x;
-  const int px = tx * kTile + (tid & 15), py = ty * kTile + (tid >> 4);
-  const bool inside = px < P.W && py < P.H;
+  const int px = tx * kTile + (tid & 15);
+  const int py0 = ty * kTile + (tid >> 4), py1 = py0 + 8;
   int start = P.tile_offset[tile], end = P.tile_offset[tile + 1];
   start = min(start, P.cap); end = min(end, P.cap);
   const int n = end - start;
   if (n <= 0) return;
-  const size_t pix = (size_t)py * P.W + px, HW = (size_t)P.W * P.H;
-  int last = 0;
-  PixBwd st;
-  {
-    float gp[3] = {0.f, 0.f, 0.f}, gd = 0.f, Tf = 1.f;
-    if (inside) {
-      last = P.n_contrib[pix];
-      Tf = P.final_T[pix];
-      gp[0] = B.grad_color[pix]; gp[1] = B.grad_color[HW + pix]; gp[2] = B.grad_color[2 * HW + pix];
-      if (B.grad_depth) gd = B.grad_depth[pix];
+  const size_t HW = (size_t)P.W * P.H;
+  int last[2] = {0, 0};
+  v2f g0 = {0.f, 0.f}, g1 = {0.f, 0.f}, g2 = {0.f, 0.f}, gd = {0.f, 0.f};
+  v2f T = {1.f, 1.f}, Tfbg = {0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int py = q ? py1 : py0;
+    if (px < P.W && py < P.H) {
+      const size_t pix = (size_t)py * P.W + px;
+      last[q] = P.n_contrib[pix];
+      T[q] = P.final_T[pix];
+      g0[q] = B.grad_color[pix]; g1[q] = B.grad_color[HW + pix]; g2[q] = B.grad_color[2 * HW + pix];
+      if (B.grad_depth) gd[q] = B.grad_depth[pix];
+      Tfbg[q] = -T[q] * (P.bg[0] * g0[q] + P.bg[1] * g1[q] + P.bg[2] * g2[q]);
     }
-    const float bg[3] = {P.bg[0], P.bg[1], P.bg[2]};
-    pixbwd_init(st, Tf, gp, gd, bg);
   }
   if (tid == 0) s_maxlast = 0;
   __syncthreads();
-  atomicMax(&s_maxlast, last);
+  atomicMax(&s_maxlast, max(last[0], last[1]));
   __syncthreads();
   const int maxlast = s_maxlast;
-  const float fpx = (float)px, fpy = (float)py;
-  const int nbatches = (n + 255) / 256;
+  const float fpx = (float)px;
+  const v2f fpy = {(float)py0, (float)py1};
+  v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, ad = {0.f, 0.f};
+  v2f la = {0.f, 0.f};
+  float lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, lcd = 0.f;
+  const int nbatches = (n + kBwdBatch - 1) / kBwdBatch;
   for (int b = nbatches - 1; b >= 0; b--) {
-    const int base = b * 256;
-    const int nb = min(256, n - base);
+    const int base = b * kBwdBatch;
+    const int nb = min(kBwdBatch, n - base);
     __syncthreads();   // previous batch fully flushed
     int slot = -1;
+    float4 q0, q1;
     if (tid < nb) {
       const int k = start + base + tid;
       const unsigned int id = (unsigned int)P.keys[k];
       slot = B.pair_base[id] + (int)P.payload[k];
-      s_slot[tid] = slot;
       if (base < maxlast) {
         const float4* src = reinterpret_cast<const float4*>(P.rec + id);
-        s_r0[tid] = src[0]; s_r1[tid] = src[1]; s_r2[tid] = src[2];
+        q0 = src[0]; q1 = src[1];
+        const float4 q2 = src[2];
+        s_r0[tid] = make_float4(q0.x, q0.y, -0.5f * kLog2eB * q1.x, -kLog2eB * q1.y);
+        s_r1[tid] = make_float4(-0.5f * kLog2eB * q1.z, q0.w, q0.z, q2.x);
+        s_r2[tid] = make_float4(q2.y, q2.z, 0.f, 0.f);
       }
     }
     if (base >= maxlast) {   // no pixel of this tile ever reached these splats
@@ -167,40 +270,70 @@ __global__ __launch_bounds__(256) void k_blend_bwd(KP P, KB B) {
       }
       continue;
     }
+    {   // zero this wave's partials: 128 x 3 float4 per wave, 6 per lane
+      float4* pp = &s_part[wave][0][0];
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int i = 0; i < 10; i++) s_acc[tid * 10 + i] = 0.f;
+      for (int i = 0; i < (kBwdBatch * 3) / 64; i++) pp[lane + 64 * i] = z;
+    }
     __syncthreads();
+    float4 u = s_r0[nb - 1], v = s_r1[nb - 1];
+    float2 cgb = *reinterpret_cast<const float2*>(&s_r2[nb - 1]);
     for (int j = nb - 1; j >= 0; j--) {
+      // software prefetch of the next (j-1) record: LDS latency overlaps this iteration
+      const int jn = max(j - 1, 0);
+      const float4 un = s_r0[jn], vn = s_r1[jn];
+      const float2 cn = *reinterpret_cast<const float2*>(&s_r2[jn]);
+      const float dx = u.x - fpx;
+      const v2f dy = v2f{u.y, u.y} - fpy;
+      const v2f pw = dx * (u.z * dx + u.w * dy) + v.x * dy * dy;
+      const v2f G = v2f{__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
+      const v2f araw = v.y * G;
+      const v2f alpha = v2f{fminf(kAlphaMax, araw.x), fminf(kAlphaMax, araw.y)};
       const int idx = base + j;
-      bool c = false;
-      SplatGrad g;
-      if (idx < last) {
-        const float4 a = s_r0[j], bb = s_r1[j], cc = s_r2[j];
-        SplatLite s;
-        s.x = a.x; s.y = a.y; s.depth = a.z; s.o = a.w;
-        s.A = bb.x; s.B = bb.y; s.C = bb.z;
-        s.r = cc.x; s.g = cc.y; s.b = cc.z;
-        c = blend_backward_step(fpx, fpy, s, st, g);
+      const bool c0 = idx < last[0] && pw.x <= 0.f && alpha.x >= kAlphaMin;
+      const bool c1 = idx < last[1] && pw.y <= 0.f && alpha.y >= kAlphaMin;
+      if (__ballot(c0 || c1) != 0ull) {
+        const v2f ae = v2f{c0 ? alpha.x : 0.f, c1 ? alpha.y : 0.f};
+        // fold the pending layer into the accumulation behind us
+        a0 += la * (lc0 - a0); a1 += la * (lc1 - a1); a2 += la * (lc2 - a2); ad += la * (lcd - ad);
+        const v2f om = 1.f - ae;
+        const v2f rom = v2f{__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+        T *= rom;
+        v2f dLda = (v.w - a0) * g0 + (cgb.x - a1) * g1 + (cgb.y - a2) * g2 + (v.z - ad) * gd;
+        dLda = dLda * T + Tfbg * rom;
+        v2f Wt = araw * dLda;
+        Wt = v2f{c0 ? Wt.x : 0.f, c1 ? Wt.y : 0.f};
+        const v2f w = ae * T;
+        la = ae;
+        lc0 = v.w; lc1 = cgb.x; lc2 = cgb.y; lcd = v.z;
+        const v2f Wy = Wt * dy, Wyy = Wy * dy;
+        const v2f wr = w * g0, wg = w * g1, wb = w * g2, wd = w * gd;
+        float r[10];
+        const float Ws = Wt.x + Wt.y, Sy = Wy.x + Wy.y;
+        r[0] = Ws; r[1] = Ws * dx; r[2] = Sy; r[3] = r[1] * dx; r[4] = Sy * dx;
+        r[5] = Wyy.x + Wyy.y;
+        r[6] = wr.x + wr.y; r[7] = wg.x + wg.y; r[8] = wb.x + wb.y; r[9] = wd.x + wd.y;
+        wave_sum10_to_lane63(r);
+        if (lane == 63) {
+          s_part[wave][j][0] = make_float4(r[0], r[1], r[2], r[3]);
+          s_part[wave][j][1] = make_float4(r[4], r[5], r[6], r[7]);
+          *reinterpret_cast<float2*>(&s_part[wave][j][2]) = make_float2(r[8], r[9]);
+        }
       }
-      if (__ballot(c) == 0ull) continue;
-      float v[10];
-      v[0] = c ? g.gx : 0.f; v[1] = c ? g.gy : 0.f; v[2] = c ? g.gA : 0.f; v[3] = c ? g.gB : 0.f;
-      v[4] = c ? g.gC : 0.f; v[5] = c ? g.gop : 0.f; v[6] = c ? g.gr : 0.f; v[7] = c ? g.gg : 0.f;
-      v[8] = c ? g.gb : 0.f; v[9] = c ? g.gdepth : 0.f;
-#pragma unroll
-      for (int i = 0; i < 10; i++) v[i] = wave_sum_to_lane63(v[i]);
-      if (lane == 63) {
-#pragma unroll
-        for (int i = 0; i < 10; i++) atomicAdd(&s_acc[j * 10 + i], v[i]);
-      }
+      u = un; v = vn; cgb = cn;
     }
     __syncthreads();
     if (tid < nb) {
-      const float* a = &s_acc[tid * 10];
+      const float4 p0a = s_part[0][tid][0], p1a = s_part[0][tid][1], p2a = s_part[0][tid][2];
+      const float4 p0b = s_part[1][tid][0], p1b = s_part[1][tid][1], p2b = s_part[1][tid][2];
+      const float S1 = p0a.x + p0b.x, Sx = p0a.y + p0b.y, Sy = p0a.z + p0b.z;
+      const float Sxx = p0a.w + p0b.w, Sxy = p1a.x + p1b.x, Syy = p1a.y + p1b.y;
+      const float A = q1.x, Bc = q1.y, Cc = q1.z, o = q0.w;
       float4* dst = B.pair_grad + (size_t)slot * 3;
-      dst[0] = make_float4(a[0], a[1], a[2], a[3]);
-      dst[1] = make_float4(a[4], a[5], a[6], a[7]);
-      dst[2] = make_float4(a[8], a[9], 0.f, 0.f);
+      dst[0] = make_float4(-(A * Sx + Bc * Sy), -(Cc * Sy + Bc * Sx), -0.5f * Sxx, -Sxy);
+      dst[1] = make_float4(-0.5f * Syy, S1 / o, p1a.z + p1b.z, p1a.w + p1b.w);
+      dst[2] = make_float4(p2a.x + p2b.x, p2a.y + p2b.y, 0.f, 0.f);
     }
   }
 }
@@ -315,7 +448,7 @@ int launch_backward(const KP& P, const KB& B, hipStream_t st) {
   launch("scan_reduce", k_scan_reduce, dim3(nscan), dim3(256), st, P, B);
   launch("scan_sums", k_scan_sums, dim3(1), dim3(1024), st, B, nscan);
   launch("scan_write", k_scan_write, dim3(nscan), dim3(256), st, P, B);
-  launch("blend_bwd", k_blend_bwd, dim3(P.T), dim3(256), st, P, B);
+  launch("blend_bwd", k_blend_bwd, dim3(P.T), dim3(kBwdThreads), st, P, B);
   const int npre = (P.N + kPreBlock - 1) / kPreBlock;
   launch("preprocess_bwd", k_preprocess_bwd, dim3(npre), dim3(kPreBlock), st, P, B);
   launch("tau_reduce", k_tau_reduce, dim3(1), dim3(384), st, B, npre);

@@ -69,6 +69,7 @@ int fill_kp(const mgs_forward_args& a, bool need_bins, bool need_outputs, KP& P)
   P.tile_count = (int*)(g + L.tile_count);
   P.tile_offset = (int*)(g + L.tile_offset);
   P.tile_cursor = (int*)(g + L.tile_cursor);
+  P.bin_table = (int*)(g + L.bin_table);
   P.final_T = (float*)(g + L.final_T);
   P.n_contrib = (int*)(g + L.n_contrib);
   P.counters = (int*)(g + L.counters);

@@ -22,6 +22,7 @@ struct KP {
   int* tile_count;
   int* tile_offset;
   int* tile_cursor;
+  int* bin_table;          // kBinBlocks x T per-block tile histograms / bases
   float* final_T;
   int* n_contrib;
   int* counters;
@@ -51,8 +52,8 @@ constexpr uint64_t kAlign = 256;
 inline uint64_t align_up(uint64_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
 
 struct Layout {
-  uint64_t rec, pair_count, tile_count, tile_offset, tile_cursor, final_T, n_contrib, counters,
-      geom_bytes;
+  uint64_t rec, pair_count, tile_count, tile_offset, tile_cursor, bin_table, final_T, n_contrib,
+      counters, geom_bytes;
   uint64_t keys, payload, bins_bytes;
   uint64_t pair_grad, pair_base, block_sums, tau_partial, bwd_bytes;
   uint64_t pix_jac, splat_jac, sketch_bytes;
@@ -60,6 +61,9 @@ struct Layout {
 
 constexpr int kScanBlock = 2048;   // elements per block in the pair_base scan
 constexpr int kPreBlock = 256;
+constexpr int kBinBlocks = 128;    // workgroups of the LDS-privatised binning passes
+constexpr int kBinThreads = 512;
+constexpr int kBinMaxTilesLds = 12288;   // T above this falls back to global atomics
 
 inline Layout make_layout(const mgs_raster_shape& s) {
   Layout L;
@@ -73,6 +77,7 @@ inline Layout make_layout(const mgs_raster_shape& s) {
   L.tile_count = o; o = align_up(o + T * 4);
   L.tile_offset = o; o = align_up(o + (T + 1) * 4);
   L.tile_cursor = o; o = align_up(o + T * 4);
+  L.bin_table = o; o = align_up(o + (uint64_t)kBinBlocks * T * 4);
   L.final_T = o; o = align_up(o + HW * 4);
   L.n_contrib = o; o = align_up(o + HW * 4);
   L.counters = o; o = align_up(o + 16);
