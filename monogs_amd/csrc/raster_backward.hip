@@ -182,158 +182,191 @@ __global__ __launch_bounds__(256) void k_scan_write(KP P, KB B) {
 }
 
 // ---------------------------------------------------------------------------------
-// Back-to-front replay, one workgroup (2 waves) per 16x16 tile, TWO pixels per lane
-// (rows y and y+8 of the same column, so dx is shared and the fp32 work of the pair
-// packs into v_pk_* instructions).
+// Blend backward, segment-parallel.  One wave per (tile, kSeg-splat segment) work item,
+// FOUR pixels per lane (rows y, y+4, y+8, y+12 of one column: dx is shared, the fp32 work
+// packs into v_pk_*).  The forward checkpointed the per-pixel blend state (T, prefix
+// colour F) in front of every segment, so items are independent: no serial chain over a
+// tile's whole list, ~D/kSeg equal-sized items instead of T ragged ones.
 //
-// Per splat and pixel the replay produces a weight W = dL/dG * G and a blend weight
-// w = alpha * T; every screen-space gradient of the splat is a pixel sum of W or w times
-// a monomial of (dx, dy) or the pixel's upstream gradient:
+// Front-to-back replay inside the segment.  With S = C_final - F_i (colour accumulated
+// behind splat i) the derivative of the pixel w.r.t. the splat's alpha is
+//   dL/dalpha_i = sum_ch dL/dC_ch * (T_i c_ch - S_ch / (1 - alpha_i)) - T_final bg.dL/dC / (1 - alpha_i)
+// and every screen-space gradient of the splat is a pixel sum of W = dL/dG * G or of the
+// blend weight w = alpha T times a monomial of (dx, dy) / the pixel's upstream gradient:
 //   S1 = sum W, Sx = sum W dx, Sy = sum W dy, Sxx, Sxy, Syy      (mean2D, conic, opacity)
 //   Rr, Rg, Rb = sum w * dL/dC_ch,  Rd = sum w * dL/dD            (colour, depth)
-// The lane first adds its two pixels, the 10 sums are reduced over the wave with DPP,
-// written by lane 63 to the wave's own LDS partial (no atomics, fixed order =>
-// deterministic) and combined / converted by the thread that staged the splat, which
-// stores the pair's 40-B record once at its slot.
-//
-// A splat that does not contribute to a pixel is replayed as a transparent layer
-// (alpha = 0): the recurrences stay branch-free and the "colour of the previously
-// visited splat" is wave-uniform.
-constexpr int kBwdBatch = 128;
-constexpr int kBwdThreads = 128;
-constexpr float kLog2eB = 1.4426950408889634f;
+// The lane adds its four pixels, the 10 sums are reduced over the wave with DPP, lane 63
+// parks them in LDS, and after the loop each lane converts two splats' sums into the
+// 40-B pair record and stores it ONCE at the pair's slot (plain stores, no atomics,
+// fixed summation order => deterministic).
 typedef float v2f __attribute__((ext_vector_type(2)));
+constexpr float kLog2eB = 1.4426950408889634f;
 
-__global__ __launch_bounds__(kBwdThreads) void k_blend_bwd(KP P, KB B) {
-  __shared__ float4 s_r0[kBwdBatch], s_r1[kBwdBatch], s_r2[kBwdBatch];
-  __shared__ float4 s_part[2][kBwdBatch][3];
-  __shared__ int s_maxlast;
-  const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tx = tile % P.grid_x, ty = tile / P.grid_x;
-  const int px = tx * kTile + (tid & 15);
-  const int py0 = ty * kTile + (tid >> 4), py1 = py0 + 8;
+__global__ __launch_bounds__(64) void k_blend_bwd(KP P, KB B) {
+  __shared__ float4 s_r0[kSeg], s_r1[kSeg];
+  __shared__ float2 s_r2[kSeg];
+  __shared__ float4 s_out[kSeg][3];
+  const int item = blockIdx.x, lane = threadIdx.x;
+  if (item >= min(P.seg_offset[P.T], P.max_segs)) return;
+  const int tile = P.seg_tile[item];
+  const int seg = item - P.seg_offset[tile];
   int start = P.tile_offset[tile], end = P.tile_offset[tile + 1];
   start = min(start, P.cap); end = min(end, P.cap);
-  const int n = end - start;
-  if (n <= 0) return;
+  const int base = seg * kSeg;
+  const int nb = min(kSeg, end - start - base);
+  if (nb <= 0) return;
+  const int tx = tile % P.grid_x, ty = tile / P.grid_x;
+  const int px = tx * kTile + (lane & 15);
+  const int pyb = ty * kTile + (lane >> 4);
   const size_t HW = (size_t)P.W * P.H;
-  int last[2] = {0, 0};
-  v2f g0 = {0.f, 0.f}, g1 = {0.f, 0.f}, g2 = {0.f, 0.f}, gd = {0.f, 0.f};
-  v2f T = {1.f, 1.f}, Tfbg = {0.f, 0.f};
+
+  // ---- stage the segment's records (2 per lane), remember slot + raw conic ---------
+  int slot[2] = {-1, -1};
+  float4 qa[2], qb[2];
 #pragma unroll
-  for (int q = 0; q < 2; q++) {
-    const int py = q ? py1 : py0;
+  for (int h = 0; h < 2; h++) {
+    const int jj = lane + 64 * h;
+    if (jj < nb) {
+      const int k = start + base + jj;
+      const unsigned int id = (unsigned int)P.keys[k];
+      slot[h] = B.pair_base[id] + (int)P.payload[k];
+      const float4* src = reinterpret_cast<const float4*>(P.rec + id);
+      qa[h] = src[0]; qb[h] = src[1];
+      const float4 q2 = src[2];
+      s_r0[jj] = make_float4(qa[h].x, qa[h].y, -0.5f * kLog2eB * qb[h].x, -kLog2eB * qb[h].y);
+      s_r1[jj] = make_float4(-0.5f * kLog2eB * qb[h].z, qa[h].w, qa[h].z, q2.x);
+      s_r2[jj] = make_float2(q2.y, q2.z);
+    }
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    s_out[jj][0] = z; s_out[jj][1] = z; s_out[jj][2] = z;
+  }
+
+  // ---- per-pixel data: pixel q of this lane is tile pixel lane + 64 q --------------------
+  int last[4];
+  v2f gA0, gA1, gA2, gAd, gB0, gB1, gB2, gBd;        // dL/dC, dL/dD   (A: q=0,1  B: q=2,3)
+  v2f cA0, cA1, cA2, cAd, cB0, cB1, cB2, cBd;        // final colour (no background), depth
+  v2f TfA, TfB;                                        // -T_final * (bg . dL/dC)
+  v2f TA = {1.f, 1.f}, TB = {1.f, 1.f};
+  v2f fA0 = {0.f, 0.f}, fA1 = fA0, fA2 = fA0, fAd = fA0, fB0 = fA0, fB1 = fA0, fB2 = fA0, fBd = fA0;
+  const float bg0 = P.bg[0], bg1 = P.bg[1], bg2 = P.bg[2];
+  const float* ck = (seg > 0) ? P.ckpt + (size_t)item * (5 * 256) : nullptr;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int py = pyb + 4 * q;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, gd = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, cd = 0.f, tf = 0.f;
+    int l = 0;
     if (px < P.W && py < P.H) {
       const size_t pix = (size_t)py * P.W + px;
-      last[q] = P.n_contrib[pix];
-      T[q] = P.final_T[pix];
-      g0[q] = B.grad_color[pix]; g1[q] = B.grad_color[HW + pix]; g2[q] = B.grad_color[2 * HW + pix];
-      if (B.grad_depth) gd[q] = B.grad_depth[pix];
-      Tfbg[q] = -T[q] * (P.bg[0] * g0[q] + P.bg[1] * g1[q] + P.bg[2] * g2[q]);
+      l = P.n_contrib[pix];
+      g0 = B.grad_color[pix]; g1 = B.grad_color[HW + pix]; g2 = B.grad_color[2 * HW + pix];
+      if (B.grad_depth) gd = B.grad_depth[pix];
+      c0 = P.final_C[pix]; c1 = P.final_C[HW + pix]; c2 = P.final_C[2 * HW + pix];
+      cd = P.final_C[3 * HW + pix];
+      tf = -P.final_T[pix] * (bg0 * g0 + bg1 * g1 + bg2 * g2);
+    }
+    last[q] = l;
+    float t = 1.f, f0 = 0.f, f1 = 0.f, f2 = 0.f, fd = 0.f;
+    if (ck) {
+      const int p = lane + 64 * q;
+      t = ck[p]; f0 = ck[256 + p]; f1 = ck[512 + p]; f2 = ck[768 + p]; fd = ck[1024 + p];
+    }
+    const int e = q & 1;
+    if (q < 2) {
+      gA0[e] = g0; gA1[e] = g1; gA2[e] = g2; gAd[e] = gd; cA0[e] = c0; cA1[e] = c1; cA2[e] = c2;
+      cAd[e] = cd; TfA[e] = tf; TA[e] = t; fA0[e] = f0; fA1[e] = f1; fA2[e] = f2; fAd[e] = fd;
+    } else {
+      gB0[e] = g0; gB1[e] = g1; gB2[e] = g2; gBd[e] = gd; cB0[e] = c0; cB1[e] = c1; cB2[e] = c2;
+      cBd[e] = cd; TfB[e] = tf; TB[e] = t; fB0[e] = f0; fB1[e] = f1; fB2[e] = f2; fBd[e] = fd;
     }
   }
-  if (tid == 0) s_maxlast = 0;
-  __syncthreads();
-  atomicMax(&s_maxlast, max(last[0], last[1]));
-  __syncthreads();
-  const int maxlast = s_maxlast;
-  const float fpx = (float)px;
-  const v2f fpy = {(float)py0, (float)py1};
-  v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, ad = {0.f, 0.f};
-  v2f la = {0.f, 0.f};
-  float lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, lcd = 0.f;
-  const int nbatches = (n + kBwdBatch - 1) / kBwdBatch;
-  for (int b = nbatches - 1; b >= 0; b--) {
-    const int base = b * kBwdBatch;
-    const int nb = min(kBwdBatch, n - base);
-    __syncthreads();   // previous batch fully flushed
-    int slot = -1;
-    float4 q0, q1;
-    if (tid < nb) {
-      const int k = start + base + tid;
-      const unsigned int id = (unsigned int)P.keys[k];
-      slot = B.pair_base[id] + (int)P.payload[k];
-      if (base < maxlast) {
-        const float4* src = reinterpret_cast<const float4*>(P.rec + id);
-        q0 = src[0]; q1 = src[1];
-        const float4 q2 = src[2];
-        s_r0[tid] = make_float4(q0.x, q0.y, -0.5f * kLog2eB * q1.x, -kLog2eB * q1.y);
-        s_r1[tid] = make_float4(-0.5f * kLog2eB * q1.z, q0.w, q0.z, q2.x);
-        s_r2[tid] = make_float4(q2.y, q2.z, 0.f, 0.f);
-      }
-    }
-    if (base >= maxlast) {   // no pixel of this tile ever reached these splats
-      if (tid < nb) {
-        float4* dst = B.pair_grad + (size_t)slot * 3;
+  // does any pixel of the tile reach this segment?
+  int ml = max(max(last[0], last[1]), max(last[2], last[3]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) ml = max(ml, __shfl_xor(ml, off));
+  if (base >= ml) {
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+      if (slot[h] >= 0) {
+        float4* dst = B.pair_grad + (size_t)slot[h] * 3;
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         dst[0] = z; dst[1] = z; dst[2] = z;
       }
-      continue;
-    }
-    {   // zero this wave's partials: 128 x 3 float4 per wave, 6 per lane
-      float4* pp = &s_part[wave][0][0];
-      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int i = 0; i < (kBwdBatch * 3) / 64; i++) pp[lane + 64 * i] = z;
-    }
-    __syncthreads();
-    float4 u = s_r0[nb - 1], v = s_r1[nb - 1];
-    float2 cgb = *reinterpret_cast<const float2*>(&s_r2[nb - 1]);
-    for (int j = nb - 1; j >= 0; j--) {
-      // software prefetch of the next (j-1) record: LDS latency overlaps this iteration
-      const int jn = max(j - 1, 0);
-      const float4 un = s_r0[jn], vn = s_r1[jn];
-      const float2 cn = *reinterpret_cast<const float2*>(&s_r2[jn]);
-      const float dx = u.x - fpx;
-      const v2f dy = v2f{u.y, u.y} - fpy;
-      const v2f pw = dx * (u.z * dx + u.w * dy) + v.x * dy * dy;
-      const v2f G = v2f{__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
-      const v2f araw = v.y * G;
-      const v2f alpha = v2f{fminf(kAlphaMax, araw.x), fminf(kAlphaMax, araw.y)};
-      const int idx = base + j;
-      const bool c0 = idx < last[0] && pw.x <= 0.f && alpha.x >= kAlphaMin;
-      const bool c1 = idx < last[1] && pw.y <= 0.f && alpha.y >= kAlphaMin;
-      if (__ballot(c0 || c1) != 0ull) {
-        const v2f ae = v2f{c0 ? alpha.x : 0.f, c1 ? alpha.y : 0.f};
-        // fold the pending layer into the accumulation behind us
-        a0 += la * (lc0 - a0); a1 += la * (lc1 - a1); a2 += la * (lc2 - a2); ad += la * (lcd - ad);
-        const v2f om = 1.f - ae;
-        const v2f rom = v2f{__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
-        T *= rom;
-        v2f dLda = (v.w - a0) * g0 + (cgb.x - a1) * g1 + (cgb.y - a2) * g2 + (v.z - ad) * gd;
-        dLda = dLda * T + Tfbg * rom;
-        v2f Wt = araw * dLda;
-        Wt = v2f{c0 ? Wt.x : 0.f, c1 ? Wt.y : 0.f};
-        const v2f w = ae * T;
-        la = ae;
-        lc0 = v.w; lc1 = cgb.x; lc2 = cgb.y; lcd = v.z;
-        const v2f Wy = Wt * dy, Wyy = Wy * dy;
-        const v2f wr = w * g0, wg = w * g1, wb = w * g2, wd = w * gd;
-        float r[10];
-        const float Ws = Wt.x + Wt.y, Sy = Wy.x + Wy.y;
-        r[0] = Ws; r[1] = Ws * dx; r[2] = Sy; r[3] = r[1] * dx; r[4] = Sy * dx;
-        r[5] = Wyy.x + Wyy.y;
-        r[6] = wr.x + wr.y; r[7] = wg.x + wg.y; r[8] = wb.x + wb.y; r[9] = wd.x + wd.y;
-        wave_sum10_to_lane63(r);
-        if (lane == 63) {
-          s_part[wave][j][0] = make_float4(r[0], r[1], r[2], r[3]);
-          s_part[wave][j][1] = make_float4(r[4], r[5], r[6], r[7]);
-          *reinterpret_cast<float2*>(&s_part[wave][j][2]) = make_float2(r[8], r[9]);
-        }
+    return;
+  }
+  __syncthreads();
+
+  const float fpx = (float)px;
+  const v2f fpyA = {(float)pyb, (float)(pyb + 4)}, fpyB = {(float)(pyb + 8), (float)(pyb + 12)};
+  float4 u = s_r0[0], v = s_r1[0];
+  float2 cgb = s_r2[0];
+  for (int j = 0; j < nb; j++) {
+    const int jn = min(j + 1, nb - 1);
+    const float4 un = s_r0[jn], vn = s_r1[jn];
+    const float2 cn = s_r2[jn];
+    const int idx = base + j;
+    const float dx = u.x - fpx;
+    const float tA = u.z * dx;
+    const v2f dyA = v2f{u.y, u.y} - fpyA, dyB = v2f{u.y, u.y} - fpyB;
+    const v2f pwA = dx * (tA + u.w * dyA) + v.x * dyA * dyA;
+    const v2f pwB = dx * (tA + u.w * dyB) + v.x * dyB * dyB;
+    const v2f arA = v.y * v2f{__builtin_amdgcn_exp2f(pwA.x), __builtin_amdgcn_exp2f(pwA.y)};
+    const v2f arB = v.y * v2f{__builtin_amdgcn_exp2f(pwB.x), __builtin_amdgcn_exp2f(pwB.y)};
+    const v2f alA = v2f{fminf(kAlphaMax, arA.x), fminf(kAlphaMax, arA.y)};
+    const v2f alB = v2f{fminf(kAlphaMax, arB.x), fminf(kAlphaMax, arB.y)};
+    const bool k0 = idx < last[0] && pwA.x <= 0.f && alA.x >= kAlphaMin;
+    const bool k1 = idx < last[1] && pwA.y <= 0.f && alA.y >= kAlphaMin;
+    const bool k2 = idx < last[2] && pwB.x <= 0.f && alB.x >= kAlphaMin;
+    const bool k3 = idx < last[3] && pwB.y <= 0.f && alB.y >= kAlphaMin;
+    if (__ballot(k0 || k1 || k2 || k3) != 0ull) {
+      const v2f aeA = v2f{k0 ? alA.x : 0.f, k1 ? alA.y : 0.f};
+      const v2f aeB = v2f{k2 ? alB.x : 0.f, k3 ? alB.y : 0.f};
+      const v2f wA = aeA * TA, wB = aeB * TB;
+      fA0 += v.w * wA; fA1 += cgb.x * wA; fA2 += cgb.y * wA; fAd += v.z * wA;
+      fB0 += v.w * wB; fB1 += cgb.x * wB; fB2 += cgb.y * wB; fBd += v.z * wB;
+      const v2f omA = 1.f - aeA, omB = 1.f - aeB;
+      const v2f roA = v2f{__builtin_amdgcn_rcpf(omA.x), __builtin_amdgcn_rcpf(omA.y)};
+      const v2f roB = v2f{__builtin_amdgcn_rcpf(omB.x), __builtin_amdgcn_rcpf(omB.y)};
+      v2f dA = gA0 * (v.w * TA - (cA0 - fA0) * roA) + gA1 * (cgb.x * TA - (cA1 - fA1) * roA) +
+               gA2 * (cgb.y * TA - (cA2 - fA2) * roA) + gAd * (v.z * TA - (cAd - fAd) * roA) +
+               TfA * roA;
+      v2f dB = gB0 * (v.w * TB - (cB0 - fB0) * roB) + gB1 * (cgb.x * TB - (cB1 - fB1) * roB) +
+               gB2 * (cgb.y * TB - (cB2 - fB2) * roB) + gBd * (v.z * TB - (cBd - fBd) * roB) +
+               TfB * roB;
+      TA *= omA; TB *= omB;
+      v2f WA = arA * dA, WB = arB * dB;
+      WA = v2f{k0 ? WA.x : 0.f, k1 ? WA.y : 0.f};
+      WB = v2f{k2 ? WB.x : 0.f, k3 ? WB.y : 0.f};
+      const v2f WyA = WA * dyA, WyB = WB * dyB;
+      const v2f WyyA = WyA * dyA + WyB * dyB;
+      const v2f Ws2 = WA + WB, Sy2 = WyA + WyB;
+      const v2f r6 = wA * gA0 + wB * gB0, r7 = wA * gA1 + wB * gB1;
+      const v2f r8 = wA * gA2 + wB * gB2, r9 = wA * gAd + wB * gBd;
+      float r[10];
+      const float Ws = Ws2.x + Ws2.y, Sy = Sy2.x + Sy2.y;
+      r[0] = Ws; r[1] = Ws * dx; r[2] = Sy; r[3] = r[1] * dx; r[4] = Sy * dx;
+      r[5] = WyyA.x + WyyA.y;
+      r[6] = r6.x + r6.y; r[7] = r7.x + r7.y; r[8] = r8.x + r8.y; r[9] = r9.x + r9.y;
+      wave_sum10_to_lane63(r);
+      if (lane == 63) {
+        s_out[j][0] = make_float4(r[0], r[1], r[2], r[3]);
+        s_out[j][1] = make_float4(r[4], r[5], r[6], r[7]);
+        *reinterpret_cast<float2*>(&s_out[j][2]) = make_float2(r[8], r[9]);
       }
-      u = un; v = vn; cgb = cn;
     }
-    __syncthreads();
-    if (tid < nb) {
-      const float4 p0a = s_part[0][tid][0], p1a = s_part[0][tid][1], p2a = s_part[0][tid][2];
-      const float4 p0b = s_part[1][tid][0], p1b = s_part[1][tid][1], p2b = s_part[1][tid][2];
-      const float S1 = p0a.x + p0b.x, Sx = p0a.y + p0b.y, Sy = p0a.z + p0b.z;
-      const float Sxx = p0a.w + p0b.w, Sxy = p1a.x + p1b.x, Syy = p1a.y + p1b.y;
-      const float A = q1.x, Bc = q1.y, Cc = q1.z, o = q0.w;
-      float4* dst = B.pair_grad + (size_t)slot * 3;
+    u = un; v = vn; cgb = cn;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    if (slot[h] >= 0) {
+      const int jj = lane + 64 * h;
+      const float4 p0 = s_out[jj][0], p1 = s_out[jj][1], p2 = s_out[jj][2];
+      const float S1 = p0.x, Sx = p0.y, Sy = p0.z, Sxx = p0.w, Sxy = p1.x, Syy = p1.y;
+      const float A = qb[h].x, Bc = qb[h].y, Cc = qb[h].z, o = qa[h].w;
+      float4* dst = B.pair_grad + (size_t)slot[h] * 3;
       dst[0] = make_float4(-(A * Sx + Bc * Sy), -(Cc * Sy + Bc * Sx), -0.5f * Sxx, -Sxy);
-      dst[1] = make_float4(-0.5f * Syy, S1 / o, p1a.z + p1b.z, p1a.w + p1b.w);
-      dst[2] = make_float4(p2a.x + p2b.x, p2a.y + p2b.y, 0.f, 0.f);
+      dst[1] = make_float4(-0.5f * Syy, S1 / o, p1.z, p1.w);
+      dst[2] = make_float4(p2.x, p2.y, 0.f, 0.f);
     }
   }
 }
@@ -448,7 +481,7 @@ int launch_backward(const KP& P, const KB& B, hipStream_t st) {
   launch("scan_reduce", k_scan_reduce, dim3(nscan), dim3(256), st, P, B);
   launch("scan_sums", k_scan_sums, dim3(1), dim3(1024), st, B, nscan);
   launch("scan_write", k_scan_write, dim3(nscan), dim3(256), st, P, B);
-  launch("blend_bwd", k_blend_bwd, dim3(P.T), dim3(kBwdThreads), st, P, B);
+  launch("blend_bwd", k_blend_bwd, dim3(P.max_segs), dim3(64), st, P, B);
   const int npre = (P.N + kPreBlock - 1) / kPreBlock;
   launch("preprocess_bwd", k_preprocess_bwd, dim3(npre), dim3(kPreBlock), st, P, B);
   launch("tau_reduce", k_tau_reduce, dim3(1), dim3(384), st, B, npre);

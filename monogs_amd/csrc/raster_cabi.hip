@@ -71,11 +71,16 @@ int fill_kp(const mgs_forward_args& a, bool need_bins, bool need_outputs, KP& P)
   P.tile_cursor = (int*)(g + L.tile_cursor);
   P.bin_table = (int*)(g + L.bin_table);
   P.final_T = (float*)(g + L.final_T);
+  P.final_C = (float*)(g + L.final_C);
+  P.seg_offset = (int*)(g + L.seg_offset);
   P.n_contrib = (int*)(g + L.n_contrib);
   P.counters = (int*)(g + L.counters);
   char* b = (char*)a.bins;
   P.keys = b ? (unsigned long long*)(b + L.keys) : nullptr;
   P.payload = b ? (unsigned int*)(b + L.payload) : nullptr;
+  P.seg_tile = b ? (int*)(b + L.seg_tile) : nullptr;
+  P.ckpt = b ? (float*)(b + L.ckpt) : nullptr;
+  P.max_segs = (int)L.max_segs;
   P.out_color = a.out_color; P.out_depth = a.out_depth; P.out_opacity = a.out_opacity;
   P.radii = a.radii; P.n_touched = a.n_touched;
   return MGS_OK;

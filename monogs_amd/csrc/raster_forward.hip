@@ -72,37 +72,88 @@ __global__ __launch_bounds__(kPreBlock) void k_preprocess(KP P) {
 // the rows into exclusive per-block bases and the tile totals; emit mode reloads its row
 // as LDS cursors and hands out positions with returning LDS atomics.  No global atomics:
 // 2*D LDS atomics replace 2*D contended HBM-side atomics (185 + 251 us -> see DESIGN.md).
+//
+// Load balance: a lane walks its own Gaussian's tile rectangle only when that has at most
+// kBinSmallRect tiles; larger rectangles (rare, but they would stall the other 63 lanes)
+// are handed to the whole wave, 64 candidate tiles per step, with the pair index taken
+// from a ballot prefix count.
+constexpr int kBinSmallRect = 12;
+
+__device__ __forceinline__ void bin_one_pair(const KP& P, int* s_tile, int emit, int t,
+                                             unsigned long long key, unsigned int j) {
+  const int pos = atomicAdd(&s_tile[t], 1);
+  if (emit && pos < P.cap) {
+    P.keys[pos] = key;
+    P.payload[pos] = j;
+  }
+}
+
 __global__ __launch_bounds__(kBinThreads) void k_bin_lds(KP P, int emit, int per_block) {
   extern __shared__ int s_tile[];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
   int* row = P.bin_table + (size_t)blockIdx.x * P.T;
   for (int t = tid; t < P.T; t += kBinThreads) s_tile[t] = emit ? (P.tile_offset[t] + row[t]) : 0;
   __syncthreads();
   const int g0 = blockIdx.x * per_block, g1 = min(P.N, g0 + per_block);
-  for (int idx = g0 + tid; idx < g1; idx += kBinThreads) {
-    const float4 r0 = reinterpret_cast<const float4*>(P.rec + idx)[0];
-    const float4 r1 = reinterpret_cast<const float4*>(P.rec + idx)[1];
-    const int radius = __float_as_int(r1.w);
+  for (int ibase = g0; ibase < g1; ibase += kBinThreads) {
+    const int idx = ibase + tid;
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+    int radius = 0;
+    if (idx < g1) {
+      r0 = reinterpret_cast<const float4*>(P.rec + idx)[0];
+      r1 = reinterpret_cast<const float4*>(P.rec + idx)[1];
+      radius = __float_as_int(r1.w);
+    }
     int cnt = 0;
+    int rmin[2] = {0, 0}, rmax[2] = {0, 0};
+    float qmax = -1.f;
     if (radius > 0) {
-      int rmin[2], rmax[2];
       tile_rect(r0.x, r0.y, radius, P.grid_x, P.grid_y, rmin, rmax);
-      const float qmax = splat_qmax(r0.w);
-      const unsigned long long keyhi = ((unsigned long long)__float_as_uint(r0.z)) << 32;
-      for (int ty = rmin[1]; ty < rmax[1]; ty++) {
+      qmax = splat_qmax(r0.w);
+    }
+    const int rw = rmax[0] - rmin[0], area = rw * (rmax[1] - rmin[1]);
+    const unsigned long long key = (((unsigned long long)__float_as_uint(r0.z)) << 32) | (unsigned int)idx;
+    if (area > 0 && area <= kBinSmallRect) {
+      for (int ty = rmin[1]; ty < rmax[1]; ty++)
         for (int tx = rmin[0]; tx < rmax[0]; tx++) {
           if (!tile_reachable(r0.x, r0.y, r1.x, r1.y, r1.z, qmax, tx, ty, P.W, P.H)) continue;
-          const int t = ty * P.grid_x + tx;
-          const int pos = atomicAdd(&s_tile[t], 1);
-          if (emit && pos < P.cap) {
-            P.keys[pos] = keyhi | (unsigned int)idx;
-            P.payload[pos] = (unsigned int)cnt;
-          }
+          bin_one_pair(P, s_tile, emit, ty * P.grid_x + tx, key, (unsigned int)cnt);
           cnt++;
         }
-      }
     }
-    if (!emit) P.pair_count[idx] = cnt;
+    // wave-cooperative pass over the large rectangles of this wave
+    unsigned long long big = __ballot(area > kBinSmallRect);
+    while (big) {
+      const int src = __ffsll((long long)big) - 1;
+      big &= big - 1;
+      const float bx = __shfl(r0.x, src), by = __shfl(r0.y, src);
+      const float bA = __shfl(r1.x, src), bB = __shfl(r1.y, src), bC = __shfl(r1.z, src);
+      const float bq = __shfl(qmax, src);
+      const int bx0 = __shfl(rmin[0], src), by0 = __shfl(rmin[1], src);
+      const int brw = __shfl(rw, src), barea = __shfl(area, src);
+      const unsigned int klo = (unsigned int)__shfl((int)(unsigned int)key, src);
+      const unsigned int khi = (unsigned int)__shfl((int)(key >> 32), src);
+      const unsigned long long bkey = ((unsigned long long)khi << 32) | klo;
+      int total = 0;
+      for (int cb = 0; cb < barea; cb += 64) {
+        const int i = cb + lane;
+        bool ok = false;
+        int t = 0;
+        if (i < barea) {
+          const int ry = i / brw, rx = i - ry * brw;
+          ok = tile_reachable(bx, by, bA, bB, bC, bq, bx0 + rx, by0 + ry, P.W, P.H);
+          t = (by0 + ry) * P.grid_x + bx0 + rx;
+        }
+        const unsigned long long m = __ballot(ok);
+        if (ok) {
+          const int j = total + __popcll(m & ((1ull << lane) - 1ull));
+          bin_one_pair(P, s_tile, emit, t, bkey, (unsigned int)j);
+        }
+        total += __popcll(m);
+      }
+      if (lane == src) cnt = total;
+    }
+    if (!emit && idx < g1) P.pair_count[idx] = cnt;
   }
   if (!emit) {
     __syncthreads();
@@ -110,17 +161,42 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_lds(KP P, int emit, int per
   }
 }
 
-// One thread per tile: exclusive prefix down the kBinBlocks rows, total -> tile_count.
-__global__ __launch_bounds__(64) void k_bin_colsum(KP P, int nblk) {
-  const int t = blockIdx.x * 64 + threadIdx.x;
-  if (t >= P.T) return;
-  int run = 0;
-  for (int b = 0; b < nblk; b++) {
-    const int v = P.bin_table[(size_t)b * P.T + t];
-    P.bin_table[(size_t)b * P.T + t] = run;
-    run += v;
+// Exclusive prefix down the rows of bin_table, total -> tile_count.  64 tiles x 16 row
+// groups per workgroup; each thread owns kBinBlocks/8 rows in registers (independent
+// loads), the groups are stitched through LDS.
+constexpr int kColGroups = 16;
+constexpr int kColRows = kBinBlocks / kColGroups;
+
+__global__ __launch_bounds__(64 * kColGroups) void k_bin_colsum(KP P, int nblk) {
+  __shared__ int s_sum[kColGroups][64];
+  const int tl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + tl;
+  int v[kColRows];
+  int sum = 0;
+#pragma unroll
+  for (int i = 0; i < kColRows; i++) {
+    const int b = grp * kColRows + i;
+    v[i] = (t < P.T && b < nblk) ? P.bin_table[(size_t)b * P.T + t] : 0;
+    sum += v[i];
   }
-  P.tile_count[t] = run;
+  s_sum[grp][tl] = sum;
+  __syncthreads();
+  int run = 0, tot = 0;
+#pragma unroll
+  for (int g = 0; g < kColGroups; g++) {
+    const int x = s_sum[g][tl];
+    if (g < grp) run += x;
+    tot += x;
+  }
+  if (t < P.T) {
+#pragma unroll
+    for (int i = 0; i < kColRows; i++) {
+      const int b = grp * kColRows + i;
+      if (b < nblk) P.bin_table[(size_t)b * P.T + t] = run;
+      run += v[i];
+    }
+    if (grp == 0) P.tile_count[t] = tot;
+  }
 }
 
 // Fallback for images with more tiles than fit an LDS table: global atomics.
@@ -157,30 +233,43 @@ __global__ __launch_bounds__(256) void k_bin(KP P, int emit) {
 }
 
 // ---------------------------------------------------------------------------------
-// Exclusive scan of the T tile counts by one 1024-thread workgroup.
+// Exclusive scans of the T tile counts (-> tile_offset, D) and of the per-tile segment
+// counts ceil(n_t / kSeg) (-> seg_offset) by one 1024-thread workgroup.
 __global__ __launch_bounds__(1024) void k_tile_scan(KP P) {
-  __shared__ int s_sum[1024];
+  __shared__ int s_sum[1024], s_seg[1024];
   const int tid = threadIdx.x;
   const int per = (P.T + 1023) / 1024;
   const int lo = tid * per, hi = min(lo + per, P.T);
-  int local = 0;
-  for (int i = lo; i < hi; i++) local += P.tile_count[i];
+  int local = 0, lseg = 0;
+  for (int i = lo; i < hi; i++) {
+    const int c = P.tile_count[i];
+    local += c;
+    lseg += (c + kSeg - 1) / kSeg;
+  }
   s_sum[tid] = local;
+  s_seg[tid] = lseg;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {
-    int v = (tid >= off) ? s_sum[tid - off] : 0;
+    const int v = (tid >= off) ? s_sum[tid - off] : 0;
+    const int w = (tid >= off) ? s_seg[tid - off] : 0;
     __syncthreads();
     s_sum[tid] += v;
+    s_seg[tid] += w;
     __syncthreads();
   }
-  int run = s_sum[tid] - local;
+  int run = s_sum[tid] - local, rseg = s_seg[tid] - lseg;
   for (int i = lo; i < hi; i++) {
+    const int c = P.tile_count[i];
     P.tile_offset[i] = run;
-    run += P.tile_count[i];
+    P.seg_offset[i] = rseg;
+    run += c;
+    rseg += (c + kSeg - 1) / kSeg;
   }
   if (tid == 1023) {
     P.tile_offset[P.T] = s_sum[1023];
+    P.seg_offset[P.T] = s_seg[1023];
     P.counters[0] = s_sum[1023];
+    P.counters[1] = s_seg[1023];
   }
 }
 
@@ -235,6 +324,11 @@ __global__ __launch_bounds__(256) void k_tile_sort(KP P) {
   int start = P.tile_offset[tile], end = P.tile_offset[tile + 1];
   start = min(start, P.cap); end = min(end, P.cap);
   const int n = end - start;
+  {   // segment -> tile map for the segment-parallel backward
+    const int s0 = P.seg_offset[tile], ns = (n + kSeg - 1) / kSeg;
+    for (int i = tid; i < ns; i += 256)
+      if (s0 + i < P.max_segs) P.seg_tile[s0 + i] = tile;
+  }
   if (n <= 1) return;
   unsigned long long* gk = P.keys + start;
   unsigned int* gv = P.payload + start;
@@ -250,78 +344,134 @@ __global__ __launch_bounds__(256) void k_tile_sort(KP P) {
 }
 
 // ---------------------------------------------------------------------------------
-// Front-to-back blend: 256 threads = one 16x16 tile, one pixel per lane; the tile's
-// sorted splat list is staged through LDS 256 records at a time (all lanes of a wave
-// read the same record -> LDS broadcast).  The staging thread pre-multiplies the conic
-// by -0.5*log2(e) so the per-pixel evaluation is 5 FMAs + one v_exp_f32.
+// Front-to-back blend: 128 threads (2 waves) = one 16x16 tile, TWO pixels per lane (rows y
+// and y+8 of one column: dx is shared, the pair's fp32 work packs into v_pk_*).  The
+// tile's sorted splat list is staged through LDS kSeg records at a time (all lanes read
+// the same record -> LDS broadcast); the staging thread pre-multiplies the conic by
+// -0.5*log2(e) so a pixel evaluation is a few FMAs + one v_exp_f32.  At every segment
+// boundary the per-pixel blend state (T, C, D) is checkpointed so that the backward can
+// process segments independently.
 constexpr float kLog2e = 1.4426950408889634f;
+typedef float v2f __attribute__((ext_vector_type(2)));
+constexpr int kFwdThreads = 128;
+static_assert(kFwdThreads == kSeg, "one staged record per thread");
 
-__global__ __launch_bounds__(256) void k_blend_fwd(KP P) {
-  __shared__ float4 s_r0[256], s_r1[256], s_r2[256];
-  __shared__ unsigned int s_id[256];
-  __shared__ int s_cnt[256];
+__global__ __launch_bounds__(kFwdThreads) void k_blend_fwd(KP P) {
+  __shared__ float4 s_r0[kSeg], s_r1[kSeg];
+  __shared__ float2 s_r2[kSeg];
+  __shared__ unsigned int s_id[kSeg];
   const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int tx = tile % P.grid_x, ty = tile / P.grid_x;
-  const int px = tx * kTile + (tid & 15), py = ty * kTile + (tid >> 4);
-  const bool inside = px < P.W && py < P.H;
+  const int px = tx * kTile + (tid & 15);
+  const int py0 = ty * kTile + (tid >> 4), py1 = py0 + 8;
+  const bool in0 = px < P.W && py0 < P.H, in1 = px < P.W && py1 < P.H;
   int start = P.tile_offset[tile], end = P.tile_offset[tile + 1];
   start = min(start, P.cap); end = min(end, P.cap);
-  bool done = !inside;
-  float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
-  int last = 0;
-  const float fpx = (float)px, fpy = (float)py;
-  for (int base = start; base < end; base += 256) {
-    if (__syncthreads_count(done) == 256) break;
-    const int k = base + tid;
-    if (k < end) {
+  const int n = end - start;
+  const int seg0 = P.seg_offset[tile];
+  // Per-pixel state lives in VGPRs as floats (live = 1 until the pixel saturates or if it
+  // is outside the image): boolean loop-carried state would be kept as SGPR lane masks and
+  // costs three scalar instructions per mask and iteration.
+  v2f live = {in0 ? 1.f : 0.f, in1 ? 1.f : 0.f};
+  v2f T = {1.f, 1.f}, C0 = {0.f, 0.f}, C1 = {0.f, 0.f}, C2 = {0.f, 0.f}, D = {0.f, 0.f};
+  int last0 = 0, last1 = 0;
+  const float fpx = (float)px;
+  const v2f fpy = {(float)py0, (float)py1};
+  for (int base = 0; base < n; base += kSeg) {
+    if (__syncthreads_count(live.x + live.y == 0.f) == kFwdThreads) break;
+    const int k = start + base + tid;
+    if (base + tid < n) {
       const unsigned int id = (unsigned int)P.keys[k];
       const float4* src = reinterpret_cast<const float4*>(P.rec + id);
       const float4 a = src[0], b = src[1], c = src[2];
-      // (x, y, A', B') (C', opacity, depth, r) (g, b, -, -)
+      // (x, y, A', B') (C', opacity, depth, r) (g, b)
       s_r0[tid] = make_float4(a.x, a.y, -0.5f * kLog2e * b.x, -kLog2e * b.y);
       s_r1[tid] = make_float4(-0.5f * kLog2e * b.z, a.w, a.z, c.x);
-      s_r2[tid] = make_float4(c.y, c.z, 0.f, 0.f);
+      s_r2[tid] = make_float2(c.y, c.z);
       s_id[tid] = id;
     }
-    s_cnt[tid] = 0;
-    __syncthreads();
-    const int nb = min(256, end - base);
-    const int cbase = base - start;
-    for (int j = 0; j < nb; j++) {
-      if (__ballot(!done) == 0ull) break;
-      const float4 a = s_r0[j], b = s_r1[j];
-      const float2 c = *reinterpret_cast<const float2*>(&s_r2[j]);
-      const float dx = a.x - fpx, dy = a.y - fpy;
-      const float pw = dx * (a.z * dx + a.w * dy) + b.x * dy * dy;
-      const float alpha = fminf(kAlphaMax, b.y * __builtin_amdgcn_exp2f(pw));
-      const bool valid = !done && pw <= 0.f && alpha >= kAlphaMin;
-      const float test_T = T * (1.f - alpha);
-      const bool stop = valid && test_T < kTStop;
-      done = done || stop;
-      const bool contrib = valid && !stop;
-      const float w = contrib ? alpha * T : 0.f;
-      C0 += b.w * w; C1 += c.x * w; C2 += c.y * w;
-      D += b.z * w;
-      T = contrib ? test_T : T;
-      last = contrib ? (cbase + j + 1) : last;
-      const unsigned long long m = __ballot(contrib && test_T > kTouchT);
-      if (m) {
-        const int leader = __ffsll((long long)m) - 1;
-        if (lane == leader) atomicAdd(&s_cnt[j], __popcll(m));
+    if (base > 0) {   // checkpoint: state in front of this segment
+      const int sg = seg0 + base / kSeg;
+      if (sg < P.max_segs) {
+        float* ck = P.ckpt + (size_t)sg * (5 * 256);
+        ck[tid] = T.x; ck[128 + tid] = T.y;
+        ck[256 + tid] = C0.x; ck[384 + tid] = C0.y;
+        ck[512 + tid] = C1.x; ck[640 + tid] = C1.y;
+        ck[768 + tid] = C2.x; ck[896 + tid] = C2.y;
+        ck[1024 + tid] = D.x; ck[1152 + tid] = D.y;
       }
     }
     __syncthreads();
-    if (tid < nb && s_cnt[tid] > 0) atomicAdd(&P.n_touched[s_id[tid]], s_cnt[tid]);
+    const int nb = min(kSeg, n - base);
+    // n_touched of splat j of this batch accumulates in lane (j & 63), register j >> 6
+    int tc0 = 0, tc1 = 0;
+    auto blend_one = [&](const float4& u, const float4& v, const float2& cgb, int j, int& tc) {
+      const float dx = u.x - fpx;
+      const v2f dy = v2f{u.y, u.y} - fpy;
+      const v2f pw = dx * (u.z * dx + u.w * dy) + v.x * dy * dy;
+      const v2f araw = v.y * v2f{__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
+      v2f a = v2f{fminf(kAlphaMax, araw.x), fminf(kAlphaMax, araw.y)};
+      a = v2f{(pw.x <= 0.f && a.x >= kAlphaMin) ? a.x : 0.f,
+              (pw.y <= 0.f && a.y >= kAlphaMin) ? a.y : 0.f} * live;
+      const v2f test_T = T - a * T;
+      // T >= kTStop is invariant, so test_T < kTStop implies a > 0: the pixel saturates
+      // here, this splat is NOT blended and nothing after it is.
+      const bool stop0 = test_T.x < kTStop, stop1 = test_T.y < kTStop;
+      live = v2f{stop0 ? 0.f : live.x, stop1 ? 0.f : live.y};
+      a = v2f{stop0 ? 0.f : a.x, stop1 ? 0.f : a.y};
+      const v2f w = a * T;
+      C0 += v.w * w; C1 += cgb.x * w; C2 += cgb.y * w; D += v.z * w;
+      T = v2f{stop0 ? T.x : test_T.x, stop1 ? T.y : test_T.y};
+      const int idx1 = base + j + 1;
+      last0 = a.x > 0.f ? idx1 : last0;
+      last1 = a.y > 0.f ? idx1 : last1;
+      const int cnt = __popcll(__builtin_amdgcn_ballot_w64(a.x > 0.f && test_T.x > kTouchT)) +
+                      __popcll(__builtin_amdgcn_ballot_w64(a.y > 0.f && test_T.y > kTouchT));
+      tc = (lane == (j & 63)) ? cnt : tc;   // lane (j & 63) keeps splat j's count
+    };
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+      const int jlo = 64 * h, jhi = min(nb, jlo + 64);
+      int tc = 0;
+      if (jlo < jhi) {
+        // two records in flight in two register sets: the LDS reads of the next splat are
+        // issued before the current one is evaluated, without register-to-register moves
+        float4 ua = s_r0[jlo], va = s_r1[jlo];
+        float2 ca = s_r2[jlo];
+        int j = jlo;
+        for (; j + 1 < jhi; j += 2) {
+          const float4 ub = s_r0[j + 1], vb = s_r1[j + 1];
+          const float2 cb = s_r2[j + 1];
+          blend_one(ua, va, ca, j, tc);
+          const int j2 = min(j + 2, kSeg - 1);
+          ua = s_r0[j2]; va = s_r1[j2]; ca = s_r2[j2];
+          blend_one(ub, vb, cb, j + 1, tc);
+        }
+        if (j < jhi) blend_one(ua, va, ca, j, tc);
+      }
+      if (h == 0) tc0 = tc; else tc1 = tc;
+      if (jhi >= nb) break;
+    }
+    if (tc0 > 0) atomicAdd(&P.n_touched[s_id[lane]], tc0);
+    if (tc1 > 0) atomicAdd(&P.n_touched[s_id[lane + 64]], tc1);
   }
-  if (inside) {
-    const size_t pix = (size_t)py * P.W + px, HW = (size_t)P.W * P.H;
-    P.final_T[pix] = T;
-    P.n_contrib[pix] = last;
-    P.out_color[pix] = C0 + T * P.bg[0];
-    P.out_color[HW + pix] = C1 + T * P.bg[1];
-    P.out_color[2 * HW + pix] = C2 + T * P.bg[2];
-    P.out_depth[pix] = D;
-    P.out_opacity[pix] = 1.f - T;
+  const size_t HW = (size_t)P.W * P.H;
+  const float bg0 = P.bg[0], bg1 = P.bg[1], bg2 = P.bg[2];
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    if (q ? in1 : in0) {
+      const size_t pix = (size_t)(q ? py1 : py0) * P.W + px;
+      const float t = T[q];
+      P.final_T[pix] = t;
+      P.n_contrib[pix] = q ? last1 : last0;
+      P.final_C[pix] = C0[q]; P.final_C[HW + pix] = C1[q];
+      P.final_C[2 * HW + pix] = C2[q]; P.final_C[3 * HW + pix] = D[q];
+      P.out_color[pix] = C0[q] + t * bg0;
+      P.out_color[HW + pix] = C1[q] + t * bg1;
+      P.out_color[2 * HW + pix] = C2[q] + t * bg2;
+      P.out_depth[pix] = D[q];
+      P.out_opacity[pix] = 1.f - t;
+    }
   }
 }
 
@@ -340,7 +490,7 @@ int launch_forward_project(const KP& P, hipStream_t st) {
   if (P.T <= kBinMaxTilesLds) {
     const int nblk = bin_blocks(P.N), per = (P.N + nblk - 1) / nblk;
     launch_smem("bin_count", k_bin_lds, dim3(nblk), dim3(kBinThreads), sizeof(int) * (size_t)P.T, st, P, 0, per);
-    launch("bin_colsum", k_bin_colsum, dim3((P.T + 63) / 64), dim3(64), st, P, nblk);
+    launch("bin_colsum", k_bin_colsum, dim3((P.T + 63) / 64), dim3(64 * kColGroups), st, P, nblk);
   } else {
     launch("bin_count", k_bin, dim3((P.N + 255) / 256), dim3(256), st, P, 0);
   }
@@ -360,7 +510,7 @@ int launch_forward_blend(const KP& P, hipStream_t st) {
     launch("bin_emit", k_bin, dim3((P.N + 255) / 256), dim3(256), st, P, 1);
   }
   launch("tile_sort", k_tile_sort, dim3(P.T), dim3(256), st, P);
-  launch("blend_fwd", k_blend_fwd, dim3(P.T), dim3(256), st, P);
+  launch("blend_fwd", k_blend_fwd, dim3(P.T), dim3(kFwdThreads), st, P);
   return check_launch();
 }
 

@@ -24,11 +24,16 @@ struct KP {
   int* tile_cursor;
   int* bin_table;          // kBinBlocks x T per-block tile histograms / bases
   float* final_T;
+  float* final_C;          // [4][H*W] colour (without background) and depth at the end of the list
   int* n_contrib;
+  int* seg_offset;         // T+1: exclusive scan of ceil(n_t / kSeg)
   int* counters;
   // bins workspace
   unsigned long long* keys;
   unsigned int* payload;
+  int* seg_tile;           // segment -> tile
+  float* ckpt;             // per segment: [5][256] blend state (T, C0, C1, C2, D) before its first splat
+  int max_segs;
   // forward outputs
   float *out_color, *out_depth, *out_opacity;
   int *radii, *n_touched;
@@ -52,17 +57,18 @@ constexpr uint64_t kAlign = 256;
 inline uint64_t align_up(uint64_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
 
 struct Layout {
-  uint64_t rec, pair_count, tile_count, tile_offset, tile_cursor, bin_table, final_T, n_contrib,
-      counters, geom_bytes;
-  uint64_t keys, payload, bins_bytes;
+  uint64_t rec, pair_count, tile_count, tile_offset, tile_cursor, bin_table, final_T, final_C,
+      n_contrib, seg_offset, counters, geom_bytes;
+  uint64_t keys, payload, seg_tile, ckpt, max_segs, bins_bytes;
   uint64_t pair_grad, pair_base, block_sums, tau_partial, bwd_bytes;
   uint64_t pix_jac, splat_jac, sketch_bytes;
 };
 
 constexpr int kScanBlock = 2048;   // elements per block in the pair_base scan
 constexpr int kPreBlock = 256;
-constexpr int kBinBlocks = 128;    // workgroups of the LDS-privatised binning passes
-constexpr int kBinThreads = 512;
+constexpr int kSeg = 128;           // splats per blend segment (checkpoint interval)
+constexpr int kBinBlocks = 512;    // workgroups of the LDS-privatised binning passes
+constexpr int kBinThreads = 1024;
 constexpr int kBinMaxTilesLds = 12288;   // T above this falls back to global atomics
 
 inline Layout make_layout(const mgs_raster_shape& s) {
@@ -79,12 +85,17 @@ inline Layout make_layout(const mgs_raster_shape& s) {
   L.tile_cursor = o; o = align_up(o + T * 4);
   L.bin_table = o; o = align_up(o + (uint64_t)kBinBlocks * T * 4);
   L.final_T = o; o = align_up(o + HW * 4);
+  L.final_C = o; o = align_up(o + HW * 16);
   L.n_contrib = o; o = align_up(o + HW * 4);
+  L.seg_offset = o; o = align_up(o + (T + 1) * 4);
   L.counters = o; o = align_up(o + 16);
   L.geom_bytes = o;
   o = 0;
   L.keys = o; o = align_up(o + cap * 8);
   L.payload = o; o = align_up(o + cap * 4);
+  L.max_segs = cap / kSeg + T;
+  L.seg_tile = o; o = align_up(o + L.max_segs * 4);
+  L.ckpt = o; o = align_up(o + L.max_segs * 5 * 256 * 4);
   L.bins_bytes = o;
   o = 0;
   L.pair_grad = o; o = align_up(o + cap * 48);

@@ -67,6 +67,15 @@ struct Camera {
 
 MGS_HD float clampf(float v, float lo, float hi) { return fminf(hi, fmaxf(lo, v)); }
 
+// 1/x: one v_rcp_f32 on the device (1 ulp), exact division on the host.
+MGS_HD float fast_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rcpf(x);
+#else
+  return 1.0f / x;
+#endif
+}
+
 // R(q) for q = (r,x,y,z), used as given (no normalisation), row-major R[3*i+j].
 MGS_HD void quat_to_rot(const float q[4], float R[9]) {
   const float r = q[0], x = q[1], y = q[2], z = q[3];
@@ -251,14 +260,14 @@ MGS_HD bool tile_reachable(float x, float y, float A, float B, float C, float qm
   if (lx <= 0.f && hx >= 0.f && ly <= 0.f && hy >= 0.f) return true;
   float qmin = 3.4e38f;
   {  // edges dx = lx, dx = hx
-    const float invC = 1.0f / C;
+    const float invC = fast_rcp(C);
     float dy = clampf(-B * lx * invC, ly, hy);
     qmin = fminf(qmin, A * lx * lx + 2.f * B * lx * dy + C * dy * dy);
     dy = clampf(-B * hx * invC, ly, hy);
     qmin = fminf(qmin, A * hx * hx + 2.f * B * hx * dy + C * dy * dy);
   }
   {  // edges dy = ly, dy = hy
-    const float invA = 1.0f / A;
+    const float invA = fast_rcp(A);
     float dx = clampf(-B * ly * invA, lx, hx);
     qmin = fminf(qmin, A * dx * dx + 2.f * B * dx * ly + C * ly * ly);
     dx = clampf(-B * hy * invA, lx, hx);
