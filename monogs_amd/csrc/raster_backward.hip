@@ -202,10 +202,12 @@ __global__ __launch_bounds__(256) void k_scan_write(KP P, KB B) {
 typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr float kLog2eB = 1.4426950408889634f;
 
+template <bool SKETCH>
 __global__ __launch_bounds__(64) void k_blend_bwd(KP P, KB B) {
   __shared__ float4 s_r0[kSeg], s_r1[kSeg];
   __shared__ float2 s_r2[kSeg];
   __shared__ float4 s_out[kSeg][3];
+  __shared__ float4 s_coef[SKETCH ? kSeg : 1][9];   // per splat: 6 tau components x 6 coefficients
   const int item = blockIdx.x, lane = threadIdx.x;
   if (item >= min(P.seg_offset[P.T], P.max_segs)) return;
   const int tile = P.seg_tile[item];
@@ -236,6 +238,11 @@ __global__ __launch_bounds__(64) void k_blend_bwd(KP P, KB B) {
       s_r0[jj] = make_float4(qa[h].x, qa[h].y, -0.5f * kLog2eB * qb[h].x, -kLog2eB * qb[h].y);
       s_r1[jj] = make_float4(-0.5f * kLog2eB * qb[h].z, qa[h].w, qa[h].z, q2.x);
       s_r2[jj] = make_float2(q2.y, q2.z);
+      if constexpr (SKETCH) {
+        const float4* cj = reinterpret_cast<const float4*>(B.splat_jac + (size_t)id * 36);
+#pragma unroll
+        for (int i = 0; i < 9; i++) s_coef[jj][i] = cj[i];
+      }
     }
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     s_out[jj][0] = z; s_out[jj][1] = z; s_out[jj][2] = z;
@@ -295,6 +302,9 @@ __global__ __launch_bounds__(64) void k_blend_bwd(KP P, KB B) {
   }
   __syncthreads();
 
+  v2f JA[6], JB[6];   // sketch mode: per-pixel pose-Jacobian rows of this segment
+#pragma unroll
+  for (int t = 0; t < 6; t++) { JA[t] = v2f{0.f, 0.f}; JB[t] = v2f{0.f, 0.f}; }
   const float fpx = (float)px;
   const v2f fpyA = {(float)pyb, (float)(pyb + 4)}, fpyB = {(float)(pyb + 8), (float)(pyb + 12)};
   float4 u = s_r0[0], v = s_r1[0];
@@ -341,6 +351,21 @@ __global__ __launch_bounds__(64) void k_blend_bwd(KP P, KB B) {
       const v2f Ws2 = WA + WB, Sy2 = WyA + WyB;
       const v2f r6 = wA * gA0 + wB * gB0, r7 = wA * gA1 + wB * gB1;
       const v2f r8 = wA * gA2 + wB * gB2, r9 = wA * gAd + wB * gBd;
+      if constexpr (SKETCH) {
+        // J_t += W (c0 dx + c1 dy + c2 dx^2 + c3 dx dy + c4 dy^2) + (w dL/dD) c5
+        const v2f XA1 = WA * dx, XB1 = WB * dx;
+        const v2f XA3 = XA1 * dx, XB3 = XB1 * dx, XA4 = XA1 * dyA, XB4 = XB1 * dyB;
+        const v2f XA5 = WyA * dyA, XB5 = WyB * dyB;
+        const v2f XA6 = wA * gAd, XB6 = wB * gBd;
+        const float* cf = reinterpret_cast<const float*>(&s_coef[j][0]);
+#pragma unroll
+        for (int t = 0; t < 6; t++) {
+          const float c0 = cf[6 * t], c1 = cf[6 * t + 1], c2 = cf[6 * t + 2], c3 = cf[6 * t + 3],
+                      c4 = cf[6 * t + 4], c5 = cf[6 * t + 5];
+          JA[t] += c0 * XA1 + c1 * WyA + c2 * XA3 + c3 * XA4 + c4 * XA5 + c5 * XA6;
+          JB[t] += c0 * XB1 + c1 * WyB + c2 * XB3 + c3 * XB4 + c4 * XB5 + c5 * XB6;
+        }
+      }
       float r[10];
       const float Ws = Ws2.x + Ws2.y, Sy = Sy2.x + Sy2.y;
       r[0] = Ws; r[1] = Ws * dx; r[2] = Sy; r[3] = r[1] * dx; r[4] = Sy * dx;
@@ -355,6 +380,22 @@ __global__ __launch_bounds__(64) void k_blend_bwd(KP P, KB B) {
     }
     u = un; v = vn; cgb = cn;
   }
+  if constexpr (SKETCH) {
+    // pixel rows of different segments of a tile meet in pix_jac: float atomics, planar
+    // [6][H*W] so a wave instruction covers 16-pixel runs of contiguous addresses
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int py = pyb + 4 * q;
+      if (px < P.W && py < P.H) {
+        const size_t pix = (size_t)py * P.W + px;
+#pragma unroll
+        for (int t = 0; t < 6; t++) {
+          const float val = (q < 2) ? JA[t][q & 1] : JB[t][q & 1];
+          atomicAdd(&B.pix_jac[(size_t)t * HW + pix], val);
+        }
+      }
+    }
+  }
   __syncthreads();
 #pragma unroll
   for (int h = 0; h < 2; h++) {
@@ -368,6 +409,89 @@ __global__ __launch_bounds__(64) void k_blend_bwd(KP P, KB B) {
       dst[1] = make_float4(-0.5f * Syy, S1 / o, p1.z, p1.w);
       dst[2] = make_float4(p2.x, p2.y, 0.f, 0.f);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Sketched pose Jacobian (rogerhh fork: slam_frontend.py:269-338 producer, :654-669
+// consumer; contract row a9).  For backward call #r the extension must return
+//   grad_sketch_dtau[s, k, :] = sum over pixels p with sketch_indices[r, s, p] == k of
+//                               dL/dpixel_p . d pixel_p / d tau          (tau = [rho; theta])
+// i.e. bucket sums of per-PIXEL Jacobian rows, which a per-Gaussian reduction cannot
+// give.  Three steps:
+//   k_sketch_prep    per Gaussian: d(x, y, A, B, C, depth)/d tau (6 x 6) by six unit-gradient
+//                    calls of the same chain used for the ordinary backward, folded with the
+//                    conic into 36 polynomial coefficients
+//   k_blend_bwd<1>   per (pixel, splat): J_p += W * poly(dx, dy) + w dL/dD * c  (6 components)
+//   k_sketch_bucket  per pixel: J_p -> LDS-privatised bucket table -> grad_sketch_dtau
+__global__ __launch_bounds__(kPreBlock) void k_sketch_prep(KP P, KB B) {
+  const int idx = blockIdx.x * kPreBlock + threadIdx.x;
+  if (idx >= P.N) return;
+  const float4 r1 = reinterpret_cast<const float4*>(P.rec + idx)[1];
+  float* out = B.splat_jac + (size_t)idx * 36;
+  if (__float_as_int(r1.w) <= 0) return;    // never staged by a blend item
+  Camera cam;
+  load_camera_b(cam, P);
+  const float p[3] = {P.means[3 * idx], P.means[3 * idx + 1], P.means[3 * idx + 2]};
+  float sc[3], q[4], c6[6];
+  const float *psc = nullptr, *pq = nullptr, *pc6 = nullptr;
+  if (P.covp) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) c6[i] = P.covp[6 * (size_t)idx + i];
+    pc6 = c6;
+  } else {
+    sc[0] = P.scales[3 * idx]; sc[1] = P.scales[3 * idx + 1]; sc[2] = P.scales[3 * idx + 2];
+    const float4 qq = reinterpret_cast<const float4*>(P.rots)[idx];
+    q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w;
+    psc = sc; pq = q;
+  }
+  float M[6][6];   // rows: x, y, A, B, C, depth ; columns: tau
+#pragma unroll
+  for (int row = 0; row < 6; row++) {
+    const float g_xy[2] = {row == 0 ? 1.f : 0.f, row == 1 ? 1.f : 0.f};
+    const float g_con[3] = {row == 2 ? 1.f : 0.f, row == 3 ? 1.f : 0.f, row == 4 ? 1.f : 0.f};
+    GaussGrad gg;
+    project_gaussian_backward(cam, p, psc, pq, pc6, g_xy, g_con, 0.f, row == 5 ? 1.f : 0.f, gg);
+#pragma unroll
+    for (int t = 0; t < 6; t++) M[row][t] = gg.dtau[t];
+  }
+  const float A = r1.x, Bc = r1.y, Cc = r1.z;
+#pragma unroll
+  for (int t = 0; t < 6; t++) {
+    out[6 * t + 0] = -(A * M[0][t] + Bc * M[1][t]);
+    out[6 * t + 1] = -(Bc * M[0][t] + Cc * M[1][t]);
+    out[6 * t + 2] = -0.5f * M[2][t];
+    out[6 * t + 3] = -M[3][t];
+    out[6 * t + 4] = -0.5f * M[4][t];
+    out[6 * t + 5] = M[5][t];
+  }
+}
+
+constexpr int kBucketBlocks = 128;
+
+__global__ __launch_bounds__(256) void k_sketch_bucket(KP P, KB B) {
+  extern __shared__ float s_acc[];    // stack * sketch * 6
+  const int nacc = B.stack_dim * B.sketch_dim * 6;
+  const size_t HW = (size_t)P.W * P.H;
+  for (int i = threadIdx.x; i < nacc; i += 256) s_acc[i] = 0.f;
+  __syncthreads();
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < HW; p += (size_t)gridDim.x * 256) {
+    float J[6];
+#pragma unroll
+    for (int t = 0; t < 6; t++) J[t] = B.pix_jac[(size_t)t * HW + p];
+    for (int s = 0; s < B.stack_dim; s++) {
+      const int k = B.sketch_idx[(size_t)s * HW + p];
+      if (k >= 0 && k < B.sketch_dim) {
+        float* a = &s_acc[(s * B.sketch_dim + k) * 6];
+#pragma unroll
+        for (int t = 0; t < 6; t++) atomicAdd(&a[t], J[t]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nacc; i += 256) {
+    const float v = s_acc[i];
+    if (v != 0.f) atomicAdd(&B.g_sketch[i], v);
   }
 }
 
@@ -481,7 +605,19 @@ int launch_backward(const KP& P, const KB& B, hipStream_t st) {
   launch("scan_reduce", k_scan_reduce, dim3(nscan), dim3(256), st, P, B);
   launch("scan_sums", k_scan_sums, dim3(1), dim3(1024), st, B, nscan);
   launch("scan_write", k_scan_write, dim3(nscan), dim3(256), st, P, B);
-  launch("blend_bwd", k_blend_bwd, dim3(P.max_segs), dim3(64), st, P, B);
+  if (B.sketch_mode != 0) {
+    const size_t HW = (size_t)P.W * P.H;
+    const size_t nacc = (size_t)B.stack_dim * B.sketch_dim * 6;
+    if (nacc * sizeof(float) > 64 * 1024) return MGS_ERR_UNSUPPORTED;
+    if (hipMemsetAsync(B.pix_jac, 0, HW * 6 * sizeof(float), st) != hipSuccess ||
+        hipMemsetAsync(B.g_sketch, 0, nacc * sizeof(float), st) != hipSuccess)
+      return MGS_ERR_LAUNCH;
+    launch("sketch_prep", k_sketch_prep, dim3((P.N + kPreBlock - 1) / kPreBlock), dim3(kPreBlock), st, P, B);
+    launch("blend_bwd_sketch", k_blend_bwd<true>, dim3(P.max_segs), dim3(64), st, P, B);
+    launch_smem("sketch_bucket", k_sketch_bucket, dim3(kBucketBlocks), dim3(256), nacc * sizeof(float), st, P, B);
+  } else {
+    launch("blend_bwd", k_blend_bwd<false>, dim3(P.max_segs), dim3(64), st, P, B);
+  }
   const int npre = (P.N + kPreBlock - 1) / kPreBlock;
   launch("preprocess_bwd", k_preprocess_bwd, dim3(npre), dim3(kPreBlock), st, P, B);
   launch("tau_reduce", k_tau_reduce, dim3(1), dim3(384), st, B, npre);

@@ -138,7 +138,10 @@ int32_t mgs_raster_backward(const mgs_backward_args* args, void* stream) {
   if (!args->grad_color || !args->bwd || !args->grad_means3D || !args->grad_means2D ||
       !args->grad_colors || !args->grad_opacities || !args->grad_tau)
     return MGS_ERR_BAD_ARGUMENT;
-  if (args->sketch_mode != 0) return MGS_ERR_UNSUPPORTED;
+  if (args->sketch_mode != 0 &&
+      (!args->sketch_indices || !args->grad_sketch_dtau || !args->sketch_ws ||
+       args->sketch_dim < 1 || args->stack_dim < 1))
+    return MGS_ERR_BAD_ARGUMENT;
   const Layout L = make_layout(args->fwd.shape);
   KB B;
   B.grad_color = args->grad_color; B.grad_depth = args->grad_depth;
@@ -151,8 +154,11 @@ int32_t mgs_raster_backward(const mgs_backward_args* args, void* stream) {
   B.g_colors = args->grad_colors; B.g_opac = args->grad_opacities;
   B.g_scales = args->grad_scales; B.g_rots = args->grad_rotations; B.g_cov = args->grad_cov3D;
   B.g_tau = args->grad_tau;
-  B.sketch_mode = 0; B.sketch_dim = 0; B.stack_dim = 0; B.sketch_idx = nullptr;
-  B.g_sketch = nullptr; B.pix_jac = nullptr; B.splat_jac = nullptr;
+  B.sketch_mode = args->sketch_mode; B.sketch_dim = args->sketch_dim; B.stack_dim = args->stack_dim;
+  B.sketch_idx = args->sketch_indices; B.g_sketch = args->grad_sketch_dtau;
+  char* sw = (char*)args->sketch_ws;
+  B.pix_jac = sw ? (float*)(sw + L.pix_jac) : nullptr;
+  B.splat_jac = sw ? (float*)(sw + L.splat_jac) : nullptr;
   return launch_backward(P, B, (hipStream_t)stream);
 }
 

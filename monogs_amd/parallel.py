@@ -45,9 +45,12 @@ class FlatGradBucket:
         self.radii = torch.empty(self.N, dtype=torch.int32, device=dev)
 
     def pack(self, means2D_grad: torch.Tensor, radii: torch.Tensor) -> None:
-        parts = [p.grad.reshape(-1) for p in self.params]
-        parts.append(torch.linalg.norm(means2D_grad[:, :2], dim=-1))
-        parts.append((radii > 0).to(torch.float32))
+        """Single local view: statistics derived from its means2D.grad and radii."""
+        self.pack_stats(torch.linalg.norm(means2D_grad[:, :2], dim=-1),
+                        (radii > 0).to(torch.float32), radii)
+
+    def pack_stats(self, grad_norm: torch.Tensor, denom: torch.Tensor, radii: torch.Tensor) -> None:
+        parts = [p.grad.reshape(-1) for p in self.params] + [grad_norm, denom]
         torch.cat(parts, out=self.flat)
         self.radii.copy_(radii)
 
@@ -61,8 +64,16 @@ class FlatGradBucket:
         denom = self.flat[off + self.N:off + 2 * self.N]
         return stat, denom, self.radii
 
+    def all_reduce_stats(self, grad_norm, denom, radii, group=None):
+        """Several local views already folded into (grad_norm, denom, max radii)."""
+        self.pack_stats(grad_norm, denom, radii)
+        return self._reduce(group)
+
     def all_reduce(self, means2D_grad: torch.Tensor, radii: torch.Tensor, group=None):
         self.pack(means2D_grad, radii)
+        return self._reduce(group)
+
+    def _reduce(self, group=None):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             dist.all_reduce(self.radii, op=dist.ReduceOp.MAX, group=group)

@@ -1,0 +1,230 @@
+"""Inner-loop bodies of MonoGS tracking and mapping, driving the HIP rasteriser.
+
+Rows a12 / a13 of SURVEY §8a.  Mirrors, for the loop bodies only (keyframe management,
+densification policy, queues and GUI are out of scope):
+  * tracking, first order   /root/reference utils/slam_frontend.py:455-630
+  * tracking, second order  utils/slam_frontend.py:269-338 (sketch args), :632-710 (LM step)
+  * mapping                 utils/slam_backend.py:171-332
+Hyper-parameters default to configs/mono/tum/base_config.yaml:245-290.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from .gaussian_renderer import render
+from .losses import HuberLoss, get_loss_mapping, get_loss_tracking_per_pixel
+from .pose import SE3_exp, update_pose
+
+
+class ViewCamera(nn.Module):
+    """The subset of utils/camera_utils.py:Camera (:10-108) the loop bodies touch."""
+
+    def __init__(self, uid, image, T_w2c, projection_matrix, fovx, fovy, H, W, device,
+                 gt_depth=None):
+        super().__init__()
+        self.uid, self.device = uid, device
+        self.T = T_w2c.to(device=device, dtype=torch.float32).clone()
+        self.original_image = image.to(device)
+        self.FoVx, self.FoVy, self.image_height, self.image_width = fovx, fovy, H, W
+        self.cam_rot_delta = nn.Parameter(torch.zeros(3, device=device))
+        self.cam_trans_delta = nn.Parameter(torch.zeros(3, device=device))
+        self.exposure_eps = 1e-8
+        self.exposure_a = nn.Parameter(torch.tensor([1.0], device=device))
+        self.exposure_b = nn.Parameter(torch.tensor([0.0], device=device))
+        self.projection_matrix = projection_matrix.to(device)
+        self.rgb_pixel_mask_mapping = (self.original_image.sum(dim=0) > 0.01).view(1, H, W)
+        self.gt_depth = None if gt_depth is None else gt_depth.to(device)
+
+    @property
+    def world_view_transform(self):
+        return self.T.transpose(0, 1)
+
+    @property
+    def full_proj_transform(self):
+        return self.world_view_transform @ self.projection_matrix
+
+    @property
+    def camera_center(self):
+        return self.world_view_transform     # as in the reference (camera_utils.py:106-108)
+
+
+class GaussianParams(nn.Module):
+    """Leaf parameters + activations as GaussianModel exposes them to render()
+    (gaussian_splatting/scene/gaussian_model.py:54-102)."""
+
+    def __init__(self, xyz, log_scales, rot, opacity_logit, features_dc, features_rest=None):
+        super().__init__()
+        self._xyz = nn.Parameter(xyz.clone())
+        self._scaling = nn.Parameter(log_scales.clone())
+        self._rotation = nn.Parameter(rot.clone())
+        self._opacity = nn.Parameter(opacity_logit.clone())
+        self._features_dc = nn.Parameter(features_dc.clone())
+        rest = features_rest if features_rest is not None else features_dc.new_zeros(
+            features_dc.shape[0], 0, 3)
+        self._features_rest = nn.Parameter(rest.clone())
+        self.active_sh_degree = 0
+        self.max_sh_degree = int(math.isqrt(1 + rest.shape[1])) - 1
+
+    get_xyz = property(lambda s: s._xyz)
+    get_scaling = property(lambda s: torch.exp(s._scaling))
+    get_rotation = property(lambda s: torch.nn.functional.normalize(s._rotation))
+    get_opacity = property(lambda s: torch.sigmoid(s._opacity))
+    get_features = property(lambda s: torch.cat((s._features_dc, s._features_rest), dim=1))
+
+
+class Pipe:
+    compute_cov3D_python = False
+    convert_SHs_python = False
+
+
+DEFAULT_CONFIG = {"Training": {"monocular": True, "rgb_boundary_threshold": 0.01,
+                               "lr": {"cam_rot_delta": 0.003, "cam_trans_delta": 0.001,
+                                      "exposure_a": 0.02, "exposure_b": 0.02},
+                               "RGN": {"use_huber": True, "huber_delta": 0.01}}}
+
+
+def make_pose_optimizer(viewpoint: ViewCamera, config=DEFAULT_CONFIG):
+    lr = config["Training"]["lr"]
+    return torch.optim.Adam([
+        {"params": [viewpoint.cam_rot_delta], "lr": lr["cam_rot_delta"]},
+        {"params": [viewpoint.cam_trans_delta], "lr": lr["cam_trans_delta"]},
+        {"params": [viewpoint.exposure_a], "lr": lr["exposure_a"]},
+        {"params": [viewpoint.exposure_b], "lr": lr["exposure_b"]}])
+
+
+def tracking_step_first_order(viewpoint, gaussians, pose_optimizer, background, pipe=Pipe,
+                              config=DEFAULT_CONFIG):
+    """One first-order tracking iteration (slam_frontend.py:493-630): render, per-pixel
+    residual, Huber + L2 norm, backward, Adam on (rot, trans, exposure), update_pose."""
+    render_pkg = render(viewpoint, gaussians, pipe, background)
+    res = get_loss_tracking_per_pixel(config, render_pkg["render"], render_pkg["depth"],
+                                      render_pkg["opacity"], viewpoint)
+    rgn = config["Training"]["RGN"]
+    if rgn["use_huber"]:
+        res = HuberLoss.apply(res, rgn["huber_delta"])
+    loss = torch.norm(res.flatten(), p=2)
+    pose_optimizer.zero_grad()
+    loss.backward()
+    with torch.no_grad():
+        pose_optimizer.step()
+        converged = update_pose(viewpoint)
+    return loss.detach(), converged, render_pkg
+
+
+def gen_forward_sketch_args(height, width, repeat_dim, stack_dim, sketch_dim, device,
+                            generator: Optional[torch.Generator] = None):
+    """CountSketch bookkeeping of slam_frontend.py:269-338: every repeat draws a random
+    permutation of the pixels, cuts its first chunk*stack*sketch entries into disjoint
+    buckets of `chunk` pixels, and records the bucket id of every pixel per stack."""
+    m, d = height * width, stack_dim * sketch_dim
+    chunk = m // d
+    idx = torch.full((repeat_dim, stack_dim * m), -1, dtype=torch.int32, device=device)
+    rows = torch.empty(repeat_dim, stack_dim, sketch_dim, chunk, dtype=torch.int32, device=device)
+    cols = torch.empty_like(rows)
+    vals = torch.arange(sketch_dim, dtype=torch.int32, device=device).view(1, -1, 1).expand(
+        stack_dim, sketch_dim, chunk).reshape(-1)
+    offs = (torch.arange(stack_dim, device=device) * m).view(-1, 1, 1).expand(
+        stack_dim, sketch_dim, chunk).reshape(-1)
+    for i in range(repeat_dim):
+        perm = torch.randperm(m, device=device, generator=generator)[:chunk * d]
+        idx[i, perm + offs] = vals
+        rows[i] = (perm // width).view(stack_dim, sketch_dim, chunk).to(torch.int32)
+        cols[i] = (perm % width).view(stack_dim, sketch_dim, chunk).to(torch.int32)
+    weights = torch.randint(0, 2, (repeat_dim, height, width), device=device,
+                            generator=generator).float() * 2 - 1
+    return {"sketch_mode": 1, "repeat_dim": repeat_dim, "stack_dim": stack_dim,
+            "sketch_dim": sketch_dim,
+            "sketch_indices": idx.reshape(repeat_dim, stack_dim, height, width),
+            "rand_indices": (rows, cols), "rand_indices_row": rows, "rand_indices_col": cols,
+            "sketch_dtau": torch.empty(stack_dim, sketch_dim, 6, device=device, requires_grad=True),
+            "sketch_dexposure": torch.empty(stack_dim, sketch_dim, 2, device=device,
+                                            requires_grad=True),
+            "chunk_size": chunk, "rand_weights": weights}
+
+
+def tracking_step_second_order(viewpoint, gaussians, background, lambda_, repeat_dim=1,
+                               stack_dim=16, sketch_dim=64, pipe=Pipe, config=DEFAULT_CONFIG,
+                               generator=None):
+    """One sketched Levenberg-Marquardt iteration (slam_frontend.py:484-710): sketched
+    render, bucket-summed residual Sf, `repeat_dim` backward passes harvesting the sketched
+    Jacobian SJ[(repeat*stack*sketch), 8], damped least squares, left-multiplicative pose
+    step and exposure step."""
+    H, W = viewpoint.image_height, viewpoint.image_width
+    m, dper = H * W, stack_dim * sketch_dim
+    fsa = gen_forward_sketch_args(H, W, repeat_dim, stack_dim, sketch_dim, viewpoint.device,
+                                  generator)
+    render_pkg = render(viewpoint, gaussians, pipe, background, forward_sketch_args=fsa)
+    res = get_loss_tracking_per_pixel(config, render_pkg["render"], render_pkg["depth"],
+                                      render_pkg["opacity"], viewpoint, forward_sketch_args=fsa)
+    rgn = config["Training"]["RGN"]
+    if rgn["use_huber"]:
+        res = HuberLoss.apply(res, rgn["huber_delta"])
+    res = res.sum(dim=0) / (m / dper)
+    weighted = res * fsa["rand_weights"]
+    rows, cols = fsa["rand_indices_row"].long(), fsa["rand_indices_col"].long()
+    bi = torch.arange(repeat_dim, device=res.device).view(-1, 1, 1, 1)
+    Sf = weighted[bi, rows, cols].sum(dim=-1)
+    n = 8
+    SJ = torch.empty(repeat_dim, stack_dim, sketch_dim, n, device=res.device)
+    for i in range(repeat_dim):
+        for p in (viewpoint.cam_rot_delta, viewpoint.cam_trans_delta, viewpoint.exposure_a,
+                  viewpoint.exposure_b, fsa["sketch_dtau"], fsa["sketch_dexposure"]):
+            p.grad = None
+        weighted[i].backward(gradient=torch.ones_like(weighted[i]), retain_graph=True)
+        SJ[i] = torch.cat((fsa["sketch_dtau"].grad, fsa["sketch_dexposure"].grad), dim=2)
+    with torch.no_grad():
+        SJ = SJ.reshape(-1, n)
+        Sf = Sf.flatten()
+        A = torch.cat((SJ, torch.eye(n, device=SJ.device) * math.sqrt(lambda_)), dim=0)
+        b = torch.cat((Sf, torch.zeros(n, device=SJ.device)), dim=0)
+        x = torch.linalg.lstsq(A, -b).solution
+        # TempCamera.step (slam_frontend.py:49-53): tau = x[:6] = [trans; rot], exposure x[6:8]
+        viewpoint.T = SE3_exp(x[:6]) @ viewpoint.T
+        viewpoint.exposure_a += x[6]
+        viewpoint.exposure_b += x[7]
+    return weighted.detach().abs().sum(), x, SJ, Sf
+
+
+def mapping_step(window: List[ViewCamera], gaussians, gaussian_optimizer, keyframe_optimizer,
+                 background, pipe=Pipe, config=DEFAULT_CONFIG, pose_window=3, bucket=None):
+    """One mapping iteration over the keyframe window (slam_backend.py:171-332): render
+    every view, sum the mapping losses (+ isotropic-scale regulariser), ONE backward, the
+    densification statistics, optimiser steps and update_pose of the first pose_window
+    keyframes.  With `bucket` (monogs_amd.parallel.FlatGradBucket) the window is the LOCAL
+    shard of views and gradients/statistics are all-reduced before the optimiser step."""
+    loss = 0.0
+    pkgs = []
+    for vp in window:
+        pkg = render(vp, gaussians, pipe, background)
+        loss = loss + get_loss_mapping(config, pkg["render"], pkg["depth"], vp, pkg["opacity"])
+        pkgs.append(pkg)
+    scaling = gaussians.get_scaling
+    loss = loss + 10 * torch.abs(scaling - scaling.mean(dim=1, keepdim=True)).mean()
+    gaussian_optimizer.zero_grad(set_to_none=True)
+    if keyframe_optimizer is not None:
+        keyframe_optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    with torch.no_grad():
+        N = gaussians.get_xyz.shape[0]
+        grad_norm = torch.zeros(N, device=gaussians.get_xyz.device)
+        denom = torch.zeros_like(grad_norm)
+        max_radii = torch.zeros(N, dtype=torch.int32, device=grad_norm.device)
+        for pkg in pkgs:   # add_densification_stats (gaussian_model.py:693-697)
+            vis = pkg["visibility_filter"]
+            g2 = torch.linalg.norm(pkg["viewspace_points"].grad[:, :2], dim=-1)
+            grad_norm += torch.where(vis, g2, torch.zeros_like(g2))
+            denom += vis.float()
+            max_radii = torch.maximum(max_radii, pkg["radii"])
+        if bucket is not None:
+            grad_norm, denom, max_radii = bucket.all_reduce_stats(grad_norm, denom, max_radii)
+        gaussian_optimizer.step()
+        if keyframe_optimizer is not None:
+            keyframe_optimizer.step()
+        for vp in window[:pose_window]:
+            if vp.uid != 0:
+                update_pose(vp)
+    return loss.detach(), grad_norm, denom, max_radii

@@ -320,3 +320,169 @@ def test_knn_dist2(built):
         got = distCUDA2(pts.to(_dev())).cpu()
         want = O.dist2_knn3(pts)
         assert torch.allclose(got, want, rtol=1e-4, atol=1e-7), P
+
+
+# ---------------------------------------------------------------------------------------
+# sketched pose Jacobian (row a9) and the loop bodies (rows a12 / a13)
+# ---------------------------------------------------------------------------------------
+def test_sketched_pose_jacobian_matches_oracle(built):
+    """Same construction as the reference's only hot-path self check
+    (utils/slam_frontend.py:1031-1127): the sketched Jacobian row of every bucket must equal
+    the plain autograd gradient of that bucket's summed residual w.r.t. (trans, rot).  Here
+    the right-hand side comes from the CPU oracle instead of the extension itself."""
+    from monogs_amd import synthetic as S
+    from monogs_amd.rasterizer import GaussianRasterizer
+    from monogs_amd.slam_loops import gen_forward_sketch_args
+    from oracle import torch_raster as O
+    dev = _dev()
+    N, W, H, repeat, stack, sketch = 600, 64, 48, 2, 2, 4
+    sc = S.make_scene(N, W, H, seed=12)
+    m, s, r, o, sh = _inputs(sc)
+    s = s * 1.5
+    g = torch.Generator().manual_seed(3)
+    Aimg = torch.randn(3, H, W, generator=g)
+    Bdep = torch.randn(1, H, W, generator=g)
+    fsa = gen_forward_sketch_args(H, W, repeat, stack, sketch, "cpu", generator=g)
+    idx = fsa["sketch_indices"]                       # [repeat, stack, H, W]
+    wts = fsa["rand_weights"]                         # [repeat, H, W]
+
+    # HIP
+    L = [t.to(dev).requires_grad_() for t in (m, s, r, o, sh)]
+    theta = torch.zeros(3, device=dev, requires_grad=True)
+    rho = torch.zeros(3, device=dev, requires_grad=True)
+    sk = torch.empty(stack, sketch, 6, device=dev, requires_grad=True)
+    img, radii, dep, opa, nt = GaussianRasterizer(gpu_settings(sc.cam, sc.bg, dev))(
+        means3D=L[0], means2D=torch.zeros(N, 3, device=dev, requires_grad=True), shs=L[4],
+        opacities=L[3], scales=L[1], rotations=L[2], theta=theta, rho=rho, sketch_mode=1,
+        sketch_dim=sketch, stack_dim=stack, sketch_dtau=sk, sketch_indices=idx.to(dev))
+    res = (img * Aimg.to(dev)).sum(0) + (dep * Bdep.to(dev))[0]
+    weighted = res[None] * wts.to(dev)
+    SJ = []
+    for i in range(repeat):
+        sk.grad = None
+        theta.grad = None
+        rho.grad = None
+        weighted[i].backward(gradient=torch.ones_like(weighted[i]), retain_graph=True)
+        SJ.append(sk.grad.clone().cpu())
+        full = torch.cat([rho.grad, theta.grad]).cpu()
+        # every pixel of the permutation prefix is in exactly one bucket per repeat, so the
+        # rows of ALL stacks together add up to the pose gradient over the covered pixels
+        covered = (idx[i] >= 0).any(0)
+        if bool(covered.all()):
+            assert rel_err(SJ[-1].sum((0, 1)), full) < 2e-3
+
+    # oracle
+    Lc = [t.clone().requires_grad_() for t in (m, s, r, o, sh)]
+    th_c = torch.zeros(3, requires_grad=True)
+    rh_c = torch.zeros(3, requires_grad=True)
+    oimg, _, odep, _, _, _ = O.rasterize(Lc[0], None, Lc[4], None, Lc[3], Lc[1], Lc[2], None,
+                                         oracle_settings(sc.cam, sc.bg), th_c, rh_c)
+    ores = (oimg * Aimg).sum(0) + (odep * Bdep)[0]
+    worst = 0.0
+    scale = max(x.abs().max().item() for x in SJ)
+    for i in range(repeat):
+        ow = ores * wts[i]
+        for st_ in range(stack):
+            for k in range(sketch):
+                th_c.grad = None
+                rh_c.grad = None
+                ow[idx[i, st_] == k].sum().backward(retain_graph=True)
+                want = torch.cat([rh_c.grad, th_c.grad])
+                worst = max(worst, (SJ[i][st_, k] - want).abs().max().item())
+    assert worst <= 2e-3 * scale, (worst, scale)
+
+
+def _loop_fixture(N=4000, W=160, H=120, seed=21):
+    from monogs_amd import synthetic as S
+    from monogs_amd.slam_loops import GaussianParams, ViewCamera
+    import math
+    dev = _dev()
+    sc = S.make_scene(N, W, H, seed)
+    gauss = GaussianParams(sc.means3D.to(dev), sc.log_scales.to(dev), sc.rot.to(dev),
+                           sc.opacity_logit.to(dev), sc.features_dc.to(dev))
+    cam = sc.cam
+    fovx, fovy = 2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy)
+
+    def view(uid, T):
+        return ViewCamera(uid, torch.zeros(3, H, W), T, cam.projmatrix_raw, fovx, fovy, H, W, dev)
+
+    return sc, gauss, view, dev
+
+
+def test_tracking_first_order_recovers_a_perturbed_pose(built):
+    """Row a12: render -> per-pixel residual -> Huber/L2 -> backward -> Adam -> update_pose
+    must pull a perturbed camera back towards the pose the target image was rendered from."""
+    from monogs_amd.gaussian_renderer import render
+    from monogs_amd.pose import SE3_exp
+    from monogs_amd.slam_loops import Pipe, make_pose_optimizer, tracking_step_first_order
+    sc, gauss, view, dev = _loop_fixture()
+    bg = torch.zeros(3, device=dev)
+    gt_cam = view(1, torch.eye(4))
+    with torch.no_grad():
+        target = render(gt_cam, gauss, Pipe, bg)["render"].clone()
+    vp = view(2, SE3_exp(torch.tensor([0.02, -0.015, 0.01, 0.004, -0.006, 0.003])))
+    vp.original_image = target
+    vp.rgb_pixel_mask_mapping = (target.sum(0) > 0.01).view(1, *target.shape[1:])
+    opt = make_pose_optimizer(vp)
+    err0 = (vp.T - torch.eye(4, device=dev)).norm().item()
+    losses = []
+    for _ in range(60):
+        loss, conv, _ = tracking_step_first_order(vp, gauss, opt, bg)
+        losses.append(loss.item())
+    err1 = (vp.T - torch.eye(4, device=dev)).norm().item()
+    assert losses[-1] < 0.6 * losses[0] and err1 < 0.5 * err0, (losses[0], losses[-1], err0, err1)
+    assert vp.cam_rot_delta.abs().sum() == 0     # deltas are zeroed by update_pose
+
+
+def test_tracking_second_order_sketched_step_reduces_the_residual(built):
+    from monogs_amd.gaussian_renderer import render
+    from monogs_amd.pose import SE3_exp
+    from monogs_amd.slam_loops import Pipe, tracking_step_second_order
+    sc, gauss, view, dev = _loop_fixture()
+    bg = torch.zeros(3, device=dev)
+    with torch.no_grad():
+        target = render(view(1, torch.eye(4)), gauss, Pipe, bg)["render"].clone()
+    vp = view(2, SE3_exp(torch.tensor([0.006, -0.004, 0.003, 0.001, -0.002, 0.001])))
+    vp.original_image = target
+    vp.rgb_pixel_mask_mapping = (target.sum(0) > 0.01).view(1, *target.shape[1:])
+    gen = torch.Generator(device=dev).manual_seed(0)
+    err0 = (vp.T - torch.eye(4, device=dev)).norm().item()
+    for _ in range(6):
+        tracking_step_second_order(vp, gauss, bg, lambda_=1e-3, repeat_dim=1, stack_dim=4,
+                                   sketch_dim=16, generator=gen)
+    err1 = (vp.T - torch.eye(4, device=dev)).norm().item()
+    assert err1 < 0.5 * err0, (err0, err1)
+
+
+def test_mapping_step_over_a_keyframe_window(built):
+    """Row a13: several renders, one summed loss, one backward; the statistics consumed by
+    densification must agree with per-view recomputation."""
+    from monogs_amd.gaussian_renderer import render
+    from monogs_amd.parallel import view_pose
+    from monogs_amd.slam_loops import Pipe, mapping_step
+    sc, gauss, view, dev = _loop_fixture(N=3000)
+    bg = torch.zeros(3, device=dev)
+    window = []
+    for i in range(3):
+        v = view(i, view_pose(i))
+        v.original_image = sc.gt_image.to(dev)
+        v.rgb_pixel_mask_mapping = torch.ones(1, 120, 160, dtype=torch.bool, device=dev)
+        window.append(v)
+    opt = torch.optim.Adam([{"params": [gauss._xyz], "lr": 1e-4}, {"params": [gauss._features_dc], "lr": 2.5e-3},
+                            {"params": [gauss._opacity], "lr": 0.05}, {"params": [gauss._scaling], "lr": 1e-3},
+                            {"params": [gauss._rotation], "lr": 1e-3}])
+    kf_opt = torch.optim.Adam([p for v in window for p in (v.cam_rot_delta, v.cam_trans_delta)], lr=1e-3)
+    l0, stat, denom, radii = mapping_step(window, gauss, opt, kf_opt, bg)
+    vis = torch.zeros_like(denom)
+    rad = torch.zeros_like(radii)
+    with torch.no_grad():
+        for v in window:
+            pkg = render(v, gauss, Pipe, bg)
+            # poses moved by at most one tiny Adam step: visibility counts agree up to a few splats
+            vis += pkg["visibility_filter"].float()
+            rad = torch.maximum(rad, pkg["radii"])
+    assert (vis - denom).abs().sum() <= 0.01 * denom.sum()
+    assert stat.isfinite().all() and (stat >= 0).all() and stat.max() > 0
+    for _ in range(10):
+        l1, *_ = mapping_step(window, gauss, opt, kf_opt, bg)
+    assert l1 < l0
