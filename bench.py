@@ -38,7 +38,59 @@ def parse():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=20)
+    ap.add_argument("--no-tracking", action="store_true")
+    ap.add_argument("--tracking-iters", type=int, default=100)
     return ap.parse_args()
+
+
+def bench_tracking(sc, dev, iters):
+    """Tracking iterations/s (row a12): the loop body of utils/slam_frontend.py:455-751 on
+    the frozen SYN-C map - first order (render, Huber/L2, backward, Adam, update_pose) and
+    second order (sketched LM, repeat 1 / stack 16 / sketch 64 as in
+    configs/mono/tum/base_config.yaml:256-260).  fr3_office itself is not available offline;
+    intrinsics and image size are fr3_office's."""
+    import math
+    from monogs_amd.gaussian_renderer import render
+    from monogs_amd.pose import SE3_exp
+    from monogs_amd.slam_loops import (GaussianParams, Pipe, ViewCamera, make_pose_optimizer,
+                                       tracking_step_first_order, tracking_step_second_order)
+    cam = sc.cam
+    H, W = cam.H, cam.W
+    gauss = GaussianParams(sc.means3D.to(dev), sc.log_scales.to(dev), sc.rot.to(dev),
+                           sc.opacity_logit.to(dev), sc.features_dc.to(dev))
+    fovx, fovy = 2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy)
+    bg = torch.zeros(3, device=dev)
+
+    def view(T):
+        return ViewCamera(1, torch.zeros(3, H, W), T, cam.projmatrix_raw, fovx, fovy, H, W, dev)
+
+    with torch.no_grad():
+        target = render(view(torch.eye(4)), gauss, Pipe, bg)["render"].clone()
+    out = {}
+    for mode in ("first_order", "second_order"):
+        vp = view(SE3_exp(torch.tensor([0.01, -0.008, 0.006, 0.002, -0.003, 0.002])))
+        vp.original_image = target
+        vp.rgb_pixel_mask_mapping = (target.sum(0) > 0.01).view(1, H, W)
+        opt = make_pose_optimizer(vp)
+        gen = torch.Generator(device=dev).manual_seed(0)
+        n = iters if mode == "first_order" else max(10, iters // 4)
+
+        def it():
+            if mode == "first_order":
+                tracking_step_first_order(vp, gauss, opt, bg)
+            else:
+                tracking_step_second_order(vp, gauss, bg, lambda_=1e-3, repeat_dim=1, stack_dim=16,
+                                           sketch_dim=64, generator=gen)
+        for _ in range(5):
+            it()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            it()
+        torch.cuda.synchronize()
+        out[mode + "_iters_per_s"] = round(n / (time.perf_counter() - t0), 2)
+    out["map"] = f"frozen SYN-C map, {sc.means3D.shape[0]} Gaussians @ {W}x{H}"
+    return out
 
 
 def main():
@@ -167,6 +219,11 @@ def main():
                                   f"({N} Gaussians @ {W}x{H}), OpenMP C++ host emulation "
                                   "(oracle/host_emul.cpp)"}
 
+    # ---- tracking iterations/s on a frozen synthetic map (second BASELINE metric) ----
+    tracking = None
+    if rank == 0 and not distributed and not args.no_tracking:
+        tracking = bench_tracking(sc, dev, args.tracking_iters)
+
     if rank == 0:
         out = {
             "metric": "rasteriser fwd+bwd fps @640x480/300k Gaussians",
@@ -179,6 +236,7 @@ def main():
                        "pairs_D": D, "views_per_step": world,
                        "parallelism": f"keyframe-parallel x{world}" if distributed else "single view"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels_us": kernels,
+            "tracking": tracking,
         }
         print(json.dumps(out))
     if distributed:
