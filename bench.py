@@ -101,12 +101,17 @@ def main():
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (HIP kernels only; no CPU fallback)")
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("MGS_DIST_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:   # functional rehearsal only (e.g. 2 ranks sharing one GPU with gloo)
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import __graft_entry__ as entry
     if not os.path.exists(entry.LIB):
@@ -160,7 +165,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if distributed:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt], dtype=torch.float64,
+                            device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ms_per_step = dt / args.steps * 1e3
@@ -192,8 +198,14 @@ def main():
         }
         dom = max((k for k in kernels if k in alg), key=lambda k: kernels[k])
         achieved = alg[dom] / (kernels[dom] * 1e-6) / 1e9
+        # HBM traffic per launch from the committed PMC pass (rocprofv3 cannot run inside
+        # this process); only valid for the default workload it was collected on
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if (N, W, H) == (300_000, 640, 480) and os.path.exists(tpath):
+            traffic = json.load(open(tpath))["bytes_per_launch"].get(dom)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0,
-                    "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                     "algorithmic_bytes": alg[dom], "avg_us": kernels[dom]}
 
     # ---- CPU baseline: the C++ host emulation on the host cores (rank 0, N = 1) ----

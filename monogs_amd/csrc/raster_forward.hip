@@ -278,68 +278,106 @@ __global__ __launch_bounds__(1024) void k_tile_scan(KP P) {
 // smaller key at the lower index, comparators whose upper index is >= n are no-ops.
 // Keys are unique (depth bits | Gaussian id), so the result is a deterministic total
 // order whatever order the emit pass filled the segment in.
-template <typename KP_, typename VP_>
-__device__ __forceinline__ void bitonic_sort(KP_ key, VP_ val, int n, int tid, int nthr) {
-  int m = 1;
+//
+// Synchronisation: the m/2 comparators of a sub-stage are dealt to the waves in contiguous
+// runs, so wave w only touches elements [w*chunk, (w+1)*chunk) whenever the sub-stage's
+// block size is <= chunk.  Those sub-stages (all but 3 for m = 1024 on 4 waves) need no
+// workgroup barrier - LDS operations of one wave execute in order - only the few with
+// larger blocks are bracketed by __syncthreads().  WAVE_LOCAL = false (HBM fallback for
+// oversized tiles) keeps a barrier after every sub-stage.
+template <bool WAVE_LOCAL, typename KP_, typename VP_>
+__device__ __forceinline__ void bitonic_sort(KP_ key, VP_ val, int n, int tid) {
+  int m = 2;
   while (m < n) m <<= 1;
   const int half_m = m >> 1;
+  const int nw = WAVE_LOCAL ? max(1, min(4, m >> 7)) : 4;     // active waves
+  const int chunk = m / nw;                                   // elements owned by a wave
+  const int cpw = half_m / nw;                                // comparators per wave
+  const int wave = tid >> 6, lane = tid & 63;
+  const bool active = wave < nw;
+  bool prev_global = true;                                    // data was just loaded by all
+  auto sync = [&](bool global) {
+    if (!WAVE_LOCAL || global || prev_global) {
+      __syncthreads();
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    prev_global = global;
+  };
+  // One LDS round trip per sub-stage: all keys and payloads of the thread's comparators
+  // are read first (independent loads), swaps are written afterwards.
+  constexpr int kMaxCmp = 2;   // comparators in flight per thread (m = 1024 on 4 waves: exactly 2)
+  auto run = [&](auto&& pair_of) {
+    for (int c0 = 0; c0 < cpw; c0 += 64 * kMaxCmp) {
+      int lo[kMaxCmp], hi[kMaxCmp];
+      unsigned long long a[kMaxCmp], b[kMaxCmp];
+      unsigned int va[kMaxCmp], vb[kMaxCmp];
+#pragma unroll
+      for (int u = 0; u < kMaxCmp; u++) {
+        const int c = c0 + lane + 64 * u;
+        lo[u] = -1;
+        if (c < cpw) {
+          pair_of(wave * cpw + c, lo[u], hi[u]);
+          if (hi[u] >= n) lo[u] = -1;
+        }
+        if (lo[u] >= 0) { a[u] = key[lo[u]]; b[u] = key[hi[u]]; va[u] = val[lo[u]]; vb[u] = val[hi[u]]; }
+      }
+#pragma unroll
+      for (int u = 0; u < kMaxCmp; u++) {
+        if (lo[u] >= 0 && a[u] > b[u]) {
+          key[lo[u]] = b[u]; key[hi[u]] = a[u];
+          val[lo[u]] = vb[u]; val[hi[u]] = va[u];
+        }
+      }
+    }
+  };
   for (int k = 2; k <= m; k <<= 1) {
     {
+      sync(k > chunk);
       const int half = k >> 1;
-      for (int i = tid; i < half_m; i += nthr) {
-        const int blk = i / half, off = i - blk * half;
-        const int lo = blk * k + off, hi = blk * k + k - 1 - off;
-        if (hi < n) {
-          const unsigned long long a = key[lo], b = key[hi];
-          if (a > b) {
-            key[lo] = b; key[hi] = a;
-            const unsigned int va = val[lo]; val[lo] = val[hi]; val[hi] = va;
-          }
-        }
-      }
-      __syncthreads();
+      if (active)
+        run([&](int i, int& lo, int& hi) {
+          const int blk = i / half, off = i - blk * half;
+          lo = blk * k + off; hi = blk * k + k - 1 - off;
+        });
     }
     for (int j = k >> 2; j > 0; j >>= 1) {
-      for (int i = tid; i < half_m; i += nthr) {
-        const int lo = 2 * i - (i & (j - 1)), hi = lo + j;
-        if (hi < n) {
-          const unsigned long long a = key[lo], b = key[hi];
-          if (a > b) {
-            key[lo] = b; key[hi] = a;
-            const unsigned int va = val[lo]; val[lo] = val[hi]; val[hi] = va;
-          }
-        }
-      }
-      __syncthreads();
+      sync(2 * j > chunk);
+      if (active)
+        run([&](int i, int& lo, int& hi) {
+          lo = 2 * i - (i & (j - 1)); hi = lo + j;
+        });
     }
   }
+  __syncthreads();
 }
 
-constexpr int kSortLds = 4096;   // pairs sorted in LDS (48 KB); larger tiles sort in HBM
-
+// Two launches by tile size class, so that the common small tiles run at 12 KB of LDS per
+// workgroup (high occupancy) and only crowded tiles pay for 48 KB; tiles beyond 4096 pairs
+// sort in place in HBM with the same network.
+template <int CAP, int MIN_N>
 __global__ __launch_bounds__(256) void k_tile_sort(KP P) {
-  __shared__ unsigned long long s_key[kSortLds];
-  __shared__ unsigned int s_val[kSortLds];
+  __shared__ unsigned long long s_key[CAP];
+  __shared__ unsigned int s_val[CAP];
   const int tile = blockIdx.x, tid = threadIdx.x;
   int start = P.tile_offset[tile], end = P.tile_offset[tile + 1];
   start = min(start, P.cap); end = min(end, P.cap);
   const int n = end - start;
-  {   // segment -> tile map for the segment-parallel backward
+  if (MIN_N == 0) {   // segment -> tile map for the segment-parallel backward
     const int s0 = P.seg_offset[tile], ns = (n + kSeg - 1) / kSeg;
     for (int i = tid; i < ns; i += 256)
       if (s0 + i < P.max_segs) P.seg_tile[s0 + i] = tile;
   }
-  if (n <= 1) return;
+  if (n <= 1 || n <= MIN_N || (MIN_N == 0 && n > CAP)) return;
   unsigned long long* gk = P.keys + start;
   unsigned int* gv = P.payload + start;
-  if (n <= kSortLds) {
+  if (n <= CAP) {
     for (int i = tid; i < n; i += 256) { s_key[i] = gk[i]; s_val[i] = gv[i]; }
-    __syncthreads();
-    bitonic_sort(s_key, s_val, n, tid, 256);
+    bitonic_sort<true>(s_key, s_val, n, tid);
     for (int i = tid; i < n; i += 256) { gk[i] = s_key[i]; gv[i] = s_val[i]; }
   } else {
-    __syncthreads();
-    bitonic_sort(gk, gv, n, tid, 256);
+    bitonic_sort<false>(gk, gv, n, tid);
   }
 }
 
@@ -509,7 +547,8 @@ int launch_forward_blend(const KP& P, hipStream_t st) {
   } else {
     launch("bin_emit", k_bin, dim3((P.N + 255) / 256), dim3(256), st, P, 1);
   }
-  launch("tile_sort", k_tile_sort, dim3(P.T), dim3(256), st, P);
+  launch("tile_sort", k_tile_sort<1024, 0>, dim3(P.T), dim3(256), st, P);
+  launch("tile_sort_big", k_tile_sort<4096, 1024>, dim3(P.T), dim3(256), st, P);
   launch("blend_fwd", k_blend_fwd, dim3(P.T), dim3(kFwdThreads), st, P);
   return check_launch();
 }

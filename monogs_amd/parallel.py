@@ -75,6 +75,15 @@ class FlatGradBucket:
 
     def _reduce(self, group=None):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-            dist.all_reduce(self.radii, op=dist.ReduceOp.MAX, group=group)
+            if dist.get_backend(group) == "gloo" and self.flat.is_cuda:
+                # CPU rehearsal of the exchange (tests / single-GPU dry runs): stage through
+                # host memory; the production path is RCCL on device buffers below
+                f, r = self.flat.cpu(), self.radii.cpu()
+                dist.all_reduce(f, op=dist.ReduceOp.SUM, group=group)
+                dist.all_reduce(r, op=dist.ReduceOp.MAX, group=group)
+                self.flat.copy_(f)
+                self.radii.copy_(r)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+                dist.all_reduce(self.radii, op=dist.ReduceOp.MAX, group=group)
         return self.unpack()

@@ -486,3 +486,90 @@ def test_mapping_step_over_a_keyframe_window(built):
     for _ in range(10):
         l1, *_ = mapping_step(window, gauss, opt, kf_opt, bg)
     assert l1 < l0
+
+
+# ---------------------------------------------------------------------------------------
+# stress shapes: every alternative code path of the binning / sort / blend kernels
+# ---------------------------------------------------------------------------------------
+def _against_emulation(sc, m, s, r, o, sh, bg=None, bwd_tol=BWD_REL):
+    from monogs_amd import synthetic as S
+    from oracle.host_emul import HostEmul
+    bg = sc.bg if bg is None else bg
+    (img, radii, dep, opa, nt), L, th, rh, m2d = _run_gpu(sc, gpu_settings(sc.cam, bg, _dev()), m, s, r, o, sh)
+    em = HostEmul()
+    eimg, eradii, edep, eopa, ent = em.forward(oracle_settings(sc.cam, bg), m, sh, None, o, s, r, None,
+                                               exact_cull=False)
+    assert (img.cpu() - eimg).abs().mean().item() <= FWD_L1
+    assert (dep.cpu() - edep).abs().mean().item() <= 5e-4
+    assert (radii.cpu() != eradii).float().mean().item() <= 1e-3
+    assert (nt.cpu() != ent).float().mean().item() <= 5e-3
+    gi = img.detach().cpu().requires_grad_()
+    gd = dep.detach().cpu().requires_grad_()
+    S.synthetic_loss(gi, gd, sc).backward()
+    out = em.backward(gi.grad, gd.grad)
+    assert rel_err(L["m"].grad, out["means3D"]) <= bwd_tol
+    assert rel_err(L["sh"].grad, out["colors"]) <= bwd_tol
+    assert rel_err(L["o"].grad.reshape(-1), out["opacities"]) <= bwd_tol
+    assert rel_err(L["s"].grad, out["scales"]) <= bwd_tol
+    assert rel_err(L["r"].grad, out["rotations"]) <= bwd_tol
+    assert rel_err(torch.cat([rh.grad, th.grad]), out["tau"]) <= 2 * bwd_tol
+
+
+def test_crowded_tiles_use_the_in_memory_sort_path(built):
+    """> 4096 pairs in a tile: k_tile_sort sorts in HBM instead of LDS, many segments/tile."""
+    from monogs_amd import rasterizer as R
+    from monogs_amd import synthetic as S
+    sc = S.make_scene(24000, 32, 32, seed=31)          # 4 tiles, ~6k+ splats each
+    m, s, r, o, sh = _inputs(sc)
+    o = o * 0.15                                        # keep pixels from saturating early
+    _against_emulation(sc, m, s, r, o, sh)
+    assert R.last_stats["pairs"] > 4 * 4096
+
+
+def test_screen_filling_splats_use_the_wave_cooperative_binning(built):
+    from monogs_amd import synthetic as S
+    sc = S.make_scene(1500, 160, 120, seed=32)
+    m, s, r, o, sh = _inputs(sc)
+    s = s.clone()
+    s[::3] *= 25.0                                      # every third splat covers dozens of tiles
+    o = o * 0.3
+    _against_emulation(sc, m, s, r, o, sh)
+
+
+def test_more_tiles_than_the_lds_table_falls_back_to_global_atomics(built):
+    from monogs_amd import synthetic as S
+    W, H = 2048, 1600                                   # 128 x 100 = 12800 tiles > 12288
+    sc = S.make_scene(20000, W, H, seed=33)
+    m, s, r, o, sh = _inputs(sc)
+    s = s * 4.0
+    _against_emulation(sc, m, s, r, o, sh)
+
+
+def test_replica_sized_image_and_background(built):
+    """BASELINE config 5 image size (1200 x 680: 75 x 43 tiles, 680 is not a multiple of 16)."""
+    from monogs_amd import synthetic as S
+    sc = S.make_scene(60000, 1200, 680, seed=34)
+    m, s, r, o, sh = _inputs(sc)
+    _against_emulation(sc, m, s * 1.5, r, o, sh, bg=torch.tensor([1.0, 1.0, 1.0]))
+
+
+def test_degenerate_inputs_do_not_fault(built):
+    """Zero opacity, huge and tiny scales, points exactly on the near plane, duplicated
+    Gaussians (densify_and_clone makes exact copies, gaussian_model.py:525-560)."""
+    from monogs_amd import synthetic as S
+    sc = S.make_scene(512, 96, 64, seed=35)
+    m, s, r, o, sh = _inputs(sc)
+    m, s, o = m.clone(), s.clone(), o.clone()
+    o[:32] = 0.0
+    s[32:64] = 1e-9
+    s[64:96] = 50.0
+    m[96:128, 2] = 0.2
+    m[128:256] = m[256:384]
+    s[128:256] = s[256:384]
+    r = r.clone()
+    r[128:256] = r[256:384]
+    (img, radii, dep, opa, nt), L, th, rh, m2d = _run_gpu(sc, gpu_settings(sc.cam, sc.bg, _dev()), m, s, r, o, sh)
+    for t in (img, dep, opa, L["m"].grad, L["s"].grad, L["r"].grad, L["o"].grad, L["sh"].grad, th.grad, rh.grad):
+        assert torch.isfinite(t).all()
+    assert (radii[96:128] == 0).all()                   # z <= 0.2 is culled
+    assert (L["m"].grad[:32] == 0).all()                # opacity 0 never reaches 1/255
