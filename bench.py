@@ -136,7 +136,7 @@ def main():
     gt_img, gt_dep = sc.gt_image.to(dev), sc.gt_depth.to(dev)
     bucket = FlatGradBucket(params) if distributed else None
 
-    def step():
+    def step(exchange=True):
         for p in params:
             p.grad = None
         theta.grad = None
@@ -147,7 +147,7 @@ def main():
                                        rotations=params[2], theta=theta, rho=rho)
         loss = (img - gt_img).abs().mean() + 0.05 * (dep - gt_dep).abs().mean()
         loss.backward()
-        if bucket is not None:
+        if bucket is not None and exchange:
             bucket.all_reduce(m2d.grad, radii)
         return loss
 
@@ -180,7 +180,7 @@ def main():
         torch.cuda.synchronize()
         _cabi.profile_enable(True)
         for _ in range(args.profile_steps):
-            step()
+            step(exchange=False)   # rank-0-only pass: no collectives here
         torch.cuda.synchronize()
         prof = _cabi.profile_read()
         _cabi.profile_enable(False)
@@ -256,4 +256,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    import faulthandler
+    import traceback
+    faulthandler.enable()
+    try:
+        main()
+    except BaseException:
+        sys.stderr.write(f"[rank {os.environ.get('RANK', '0')}] bench.py failed:\n{traceback.format_exc()}\n")
+        sys.stderr.flush()
+        raise
