@@ -45,7 +45,8 @@ def parse():
 
 def bench_tracking(sc, dev, iters):
     """Tracking iterations/s (row a12): the loop body of utils/slam_frontend.py:455-751 on
-    the frozen SYN-C map - first order (render, Huber/L2, backward, Adam, update_pose) and
+    the frozen SYN-C map - first order (render, Huber/L2, backward, Adam, update_pose; once
+    with the reference's PyTorch glue, once with the fused HIP loss / optimiser+update_pose) and
     second order (sketched LM, repeat 1 / stack 16 / sketch 64 as in
     configs/mono/tum/base_config.yaml:256-260).  fr3_office itself is not available offline;
     intrinsics and image size are fr3_office's."""
@@ -53,7 +54,9 @@ def bench_tracking(sc, dev, iters):
     from monogs_amd.gaussian_renderer import render
     from monogs_amd.pose import SE3_exp
     from monogs_amd.slam_loops import (GaussianParams, Pipe, ViewCamera, make_pose_optimizer,
-                                       tracking_step_first_order, tracking_step_second_order)
+                                       tracking_step_first_order, tracking_step_first_order_fused,
+                                       tracking_step_second_order)
+    from monogs_amd.tracking_fused import FusedPoseOptimizer
     cam = sc.cam
     H, W = cam.H, cam.W
     gauss = GaussianParams(sc.means3D.to(dev), sc.log_scales.to(dev), sc.rot.to(dev),
@@ -67,20 +70,24 @@ def bench_tracking(sc, dev, iters):
     with torch.no_grad():
         target = render(view(torch.eye(4)), gauss, Pipe, bg)["render"].clone()
     out = {}
-    for mode in ("first_order", "second_order"):
+    for mode in ("first_order", "first_order_fused", "second_order", "second_order_fused"):
         vp = view(SE3_exp(torch.tensor([0.01, -0.008, 0.006, 0.002, -0.003, 0.002])))
         vp.original_image = target
         vp.rgb_pixel_mask_mapping = (target.sum(0) > 0.01).view(1, H, W)
         opt = make_pose_optimizer(vp)
+        fopt = FusedPoseOptimizer(vp)
         gen = torch.Generator(device=dev).manual_seed(0)
-        n = iters if mode == "first_order" else max(10, iters // 4)
+        n = iters if mode.startswith("first") else max(10, iters // 4)
 
         def it():
             if mode == "first_order":
                 tracking_step_first_order(vp, gauss, opt, bg)
+            elif mode == "first_order_fused":
+                tracking_step_first_order_fused(vp, gauss, fopt, bg)
             else:
                 tracking_step_second_order(vp, gauss, bg, lambda_=1e-3, repeat_dim=1, stack_dim=16,
-                                           sketch_dim=64, generator=gen)
+                                           sketch_dim=64, generator=gen,
+                                           fused_solve=mode.endswith("fused"))
         for _ in range(5):
             it()
         torch.cuda.synchronize()

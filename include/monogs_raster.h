@@ -146,6 +146,80 @@ uint64_t mgs_knn_scratch_bytes(int32_t num_points);
 int32_t mgs_knn_dist2(const float* points, int32_t num_points, float* out, void* scratch,
                       void* stream);
 
+/* ---- tracking-loop glue --------------------------------------- */
+
+/* torch.optim.Adam step (betas, eps, bias correction as PyTorch; no weight decay) on the
+ * four per-camera parameter groups of utils/slam_frontend.py:364-392, then update_pose
+ * (utils/pose_utils.py:88-98): T <- Exp([trans_delta; rot_delta]) T, deltas zeroed,
+ * *converged = |tau| < threshold.  State order in exp_avg / exp_avg_sq: rot(3), trans(3),
+ * a, b.  A NULL grad skips its group; T == NULL skips the pose update. */
+typedef struct mgs_pose_adam_args {
+  float* cam_rot_delta;        /* [3] */
+  float* cam_trans_delta;      /* [3] */
+  float* exposure_a;           /* [1] or NULL */
+  float* exposure_b;           /* [1] or NULL */
+  const float* grad_rot;
+  const float* grad_trans;
+  const float* grad_a;
+  const float* grad_b;
+  float* exp_avg;              /* [8] */
+  float* exp_avg_sq;           /* [8] */
+  float* T;                    /* [4,4] row-major world-to-camera, updated in place, or NULL */
+  int32_t* converged;          /* out, or NULL */
+  int32_t step;                /* 1-based */
+  float lr_rot, lr_trans, lr_a, lr_b;
+  float beta1, beta2, eps;
+  float converged_threshold;
+} mgs_pose_adam_args;
+
+int32_t mgs_pose_adam_step(const mgs_pose_adam_args* args, void* stream);
+
+/* Sketched Levenberg-Marquardt step (utils/slam_frontend.py:672-697 + TempCamera.step
+ * :49-53): solves (SJ^T SJ + lambda I) x = -SJ^T Sf for the 8 unknowns
+ * [trans(3), rot(3), exposure_a, exposure_b] (identical to the reference's damped
+ * torch.linalg.lstsq), writes x_out[8] and applies T <- Exp(x[:6]) T, exposure += x[6:8]
+ * (T / exposure may be NULL to only solve). */
+typedef struct mgs_lm_step_args {
+  const float* SJ;      /* [rows, 8] */
+  const float* Sf;      /* [rows] */
+  int32_t rows;
+  float lambda;         /* > 0 */
+  float* T;             /* [4,4] or NULL */
+  float* exposure_a;    /* [1] or NULL */
+  float* exposure_b;    /* [1] or NULL */
+  float* x_out;         /* [8] */
+} mgs_lm_step_args;
+
+int32_t mgs_lm_solve_step(const mgs_lm_step_args* args, void* stream);
+
+/* Monocular tracking objective (utils/slam_utils.py:188-205, :58-75; norm at
+ * utils/slam_frontend.py:596-598):
+ *   loss = || Huber_delta( opacity * mask * ((|a| + eps) * image + b - gt) ) ||_2
+ * huber_delta <= 0 disables Huber.  `partial` holds mgs_tracking_loss_partial_count floats,
+ * `scalars` 2 floats ([0] = loss, [1] = 1/loss) written by forward and read by backward. */
+typedef struct mgs_tracking_loss_args {
+  const float* image;          /* [3,H,W] */
+  const float* opacity;        /* [1,H,W] */
+  const float* gt;             /* [3,H,W] */
+  const float* mask;           /* [1,H,W] as float 0/1, or NULL */
+  const float* exposure_a;     /* [1] */
+  const float* exposure_b;     /* [1] */
+  float exposure_eps;
+  float huber_delta;
+  int64_t num_pixels;          /* H*W */
+  float* partial;
+  float* scalars;
+  /* backward only */
+  const float* grad_out;       /* [1] dL/dloss */
+  float* grad_image;           /* [3,H,W] */
+  float* grad_a;               /* [1] */
+  float* grad_b;               /* [1] */
+} mgs_tracking_loss_args;
+
+int32_t mgs_tracking_loss_partial_count(int64_t num_pixels);
+int32_t mgs_tracking_loss_forward(const mgs_tracking_loss_args* args, void* stream);
+int32_t mgs_tracking_loss_backward(const mgs_tracking_loss_args* args, void* stream);
+
 /* Per-kernel timing (diagnostics; used by bench.py for the roofline line).  While
  * enabled every kernel launch is bracketed by hipEvents on the launch stream.
  * mgs_profile_read waits for the recorded events, aggregates them by kernel name into

@@ -18,6 +18,8 @@ EXPORTS = (
     "mgs_abi_version", "mgs_status_string", "mgs_raster_workspace_query",
     "mgs_raster_forward_project", "mgs_raster_forward_blend", "mgs_raster_backward",
     "mgs_knn_scratch_bytes", "mgs_knn_dist2", "mgs_profile_enable", "mgs_profile_read",
+    "mgs_pose_adam_step", "mgs_tracking_loss_partial_count", "mgs_tracking_loss_forward",
+    "mgs_tracking_loss_backward", "mgs_lm_solve_step",
 )
 
 _fp = C.c_void_p  # device pointers travel as plain addresses
@@ -50,6 +52,25 @@ class BackwardArgs(C.Structure):
         "grad_opacities", "grad_scales", "grad_rotations", "grad_cov3D", "grad_tau")]
         + [("sketch_mode", C.c_int32), ("sketch_dim", C.c_int32), ("stack_dim", C.c_int32),
            ("sketch_indices", _fp), ("grad_sketch_dtau", _fp), ("sketch_ws", _fp)])
+
+
+class PoseAdamArgs(C.Structure):
+    _fields_ = ([(n, _fp) for n in (
+        "cam_rot_delta", "cam_trans_delta", "exposure_a", "exposure_b", "grad_rot", "grad_trans",
+        "grad_a", "grad_b", "exp_avg", "exp_avg_sq", "T", "converged")]
+        + [("step", C.c_int32)] + [(n, C.c_float) for n in (
+            "lr_rot", "lr_trans", "lr_a", "lr_b", "beta1", "beta2", "eps", "converged_threshold")])
+
+
+class LMStepArgs(C.Structure):
+    _fields_ = [("SJ", _fp), ("Sf", _fp), ("rows", C.c_int32), ("lam", C.c_float), ("T", _fp),
+                ("exposure_a", _fp), ("exposure_b", _fp), ("x_out", _fp)]
+
+
+class TrackingLossArgs(C.Structure):
+    _fields_ = ([(n, _fp) for n in ("image", "opacity", "gt", "mask", "exposure_a", "exposure_b")]
+                + [("exposure_eps", C.c_float), ("huber_delta", C.c_float), ("num_pixels", C.c_int64)]
+                + [(n, _fp) for n in ("partial", "scalars", "grad_out", "grad_image", "grad_a", "grad_b")])
 
 
 _lib = None
@@ -91,6 +112,15 @@ def lib():
     L.mgs_profile_read.restype = C.c_int32
     L.mgs_profile_read.argtypes = [C.c_int32, C.c_char_p, C.POINTER(C.c_float),
                                    C.POINTER(C.c_int32)]
+    L.mgs_pose_adam_step.restype = C.c_int32
+    L.mgs_pose_adam_step.argtypes = [C.POINTER(PoseAdamArgs), C.c_void_p]
+    L.mgs_lm_solve_step.restype = C.c_int32
+    L.mgs_lm_solve_step.argtypes = [C.POINTER(LMStepArgs), C.c_void_p]
+    L.mgs_tracking_loss_partial_count.restype = C.c_int32
+    L.mgs_tracking_loss_partial_count.argtypes = [C.c_int64]
+    for fn in (L.mgs_tracking_loss_forward, L.mgs_tracking_loss_backward):
+        fn.restype = C.c_int32
+        fn.argtypes = [C.POINTER(TrackingLossArgs), C.c_void_p]
     if L.mgs_abi_version() != ABI_VERSION:
         raise NativeLibraryError(
             f"ABI mismatch: library {L.mgs_abi_version()} vs binding {ABI_VERSION}")

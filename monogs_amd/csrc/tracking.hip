@@ -1,0 +1,306 @@
+// Tracking-loop glue fused into a handful of launches (after the
+// rasteriser the tracking iteration was dominated by ~100 tiny PyTorch kernels).
+//
+//  * k_pose_adam_update: torch.optim.Adam step for the four per-camera parameter groups
+//    (cam_rot_delta, cam_trans_delta, exposure_a, exposure_b; utils/slam_frontend.py:364-392)
+//    followed by update_pose (utils/pose_utils.py:88-98): T <- Exp([rho; theta]) T, deltas
+//    zeroed, convergence flag.  One thread; replaces ~60 launches and two host syncs.
+//  * k_track_loss_fwd / k_track_loss_bwd: monocular tracking objective
+//    || Huber( opacity * mask * ((|a|+eps) * image + b - gt) ) ||_2
+//    (utils/slam_utils.py:188-205 + :58-75 + slam_frontend.py:596-598), forward and
+//    backward (d/d image, d/d a, d/d b), HBM-bound streaming kernels.
+#include <hip/hip_runtime.h>
+
+#include "../../include/monogs_raster.h"
+#include "launch.h"
+
+namespace mgs {
+
+__device__ inline void so3_exp_V(const float th[3], float R[9], float V[9]) {
+  const float x = th[0], y = th[1], z = th[2];
+  const float W[9] = {0.f, -z, y, z, 0.f, -x, -y, x, 0.f};
+  float W2[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      W2[3 * i + j] = W[3 * i] * W[j] + W[3 * i + 1] * W[3 + j] + W[3 * i + 2] * W[6 + j];
+  const float angle = sqrtf(x * x + y * y + z * z);
+  float a, b, c, d;   // R = I + a W + b W2 ; V = I + c W + d W2
+  if (angle < 1e-5f) {
+    a = 1.f; b = 0.5f; c = 0.5f; d = 1.f / 6.f;
+  } else {
+    const float s = sinf(angle), co = cosf(angle), a2 = angle * angle;
+    a = s / angle; b = (1.f - co) / a2; c = b; d = (angle - s) / (a2 * angle);
+  }
+  for (int i = 0; i < 9; i++) {
+    const float I = (i == 0 || i == 4 || i == 8) ? 1.f : 0.f;
+    R[i] = I + a * W[i] + b * W2[i];
+    V[i] = I + c * W[i] + d * W2[i];
+  }
+}
+
+__global__ void k_pose_adam_update(mgs_pose_adam_args A) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float* P[4] = {A.cam_rot_delta, A.cam_trans_delta, A.exposure_a, A.exposure_b};
+  const float* G[4] = {A.grad_rot, A.grad_trans, A.grad_a, A.grad_b};
+  const float lr[4] = {A.lr_rot, A.lr_trans, A.lr_a, A.lr_b};
+  const int len[4] = {3, 3, 1, 1};
+  const float bc1 = 1.f - powf(A.beta1, (float)A.step);
+  const float bc2s = sqrtf(1.f - powf(A.beta2, (float)A.step));
+  int off = 0;
+  for (int g = 0; g < 4; g++) {
+    for (int i = 0; i < len[g]; i++, off++) {
+      if (!G[g]) continue;
+      const float gr = G[g][i];
+      const float m = A.beta1 * A.exp_avg[off] + (1.f - A.beta1) * gr;
+      const float v = A.beta2 * A.exp_avg_sq[off] + (1.f - A.beta2) * gr * gr;
+      A.exp_avg[off] = m; A.exp_avg_sq[off] = v;
+      const float denom = sqrtf(v) / bc2s + A.eps;
+      P[g][i] -= (lr[g] / bc1) * (m / denom);
+    }
+  }
+  if (A.T) {
+    const float th[3] = {A.cam_rot_delta[0], A.cam_rot_delta[1], A.cam_rot_delta[2]};
+    const float rho[3] = {A.cam_trans_delta[0], A.cam_trans_delta[1], A.cam_trans_delta[2]};
+    float R[9], V[9];
+    so3_exp_V(th, R, V);
+    float t[3];
+    for (int i = 0; i < 3; i++) t[i] = V[3 * i] * rho[0] + V[3 * i + 1] * rho[1] + V[3 * i + 2] * rho[2];
+    float Tn[12];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 4; j++)
+        Tn[4 * i + j] = R[3 * i] * A.T[j] + R[3 * i + 1] * A.T[4 + j] + R[3 * i + 2] * A.T[8 + j] +
+                        (j == 3 ? t[i] : 0.f) * A.T[15];
+    for (int i = 0; i < 12; i++) A.T[i] = Tn[i];
+    const float n2 = th[0] * th[0] + th[1] * th[1] + th[2] * th[2] + rho[0] * rho[0] + rho[1] * rho[1] +
+                     rho[2] * rho[2];
+    if (A.converged) *A.converged = n2 < A.converged_threshold * A.converged_threshold ? 1 : 0;
+    for (int i = 0; i < 3; i++) { A.cam_rot_delta[i] = 0.f; A.cam_trans_delta[i] = 0.f; }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+constexpr int kLossBlock = 256;
+constexpr int kLossBlocks = 512;
+
+__device__ __forceinline__ float huber(float x, float delta, float& dh) {
+  const float ax = fabsf(x);
+  if (delta <= 0.f || ax < delta) { dh = 1.f; return x; }
+  const float s = sqrtf(2.f * delta * ax - delta * delta);
+  dh = delta / s;
+  return copysignf(s, x);
+}
+
+__device__ __forceinline__ float block_sum(float v, float* s_red) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) s_red[wave] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int w = 0; w < kLossBlock / 64; w++) t += s_red[w];
+  return t;
+}
+
+// partial[b] = sum over the block's pixels of h^2 (3 channels)
+__global__ __launch_bounds__(kLossBlock) void k_track_loss_fwd(mgs_tracking_loss_args A) {
+  __shared__ float s_red[kLossBlock / 64];
+  const float gain = fabsf(A.exposure_a[0]) + A.exposure_eps, bias = A.exposure_b[0];
+  const size_t HW = (size_t)A.num_pixels;
+  float acc = 0.f;
+  for (size_t p = (size_t)blockIdx.x * kLossBlock + threadIdx.x; p < HW; p += (size_t)gridDim.x * kLossBlock) {
+    const float om = A.opacity[p] * (A.mask ? A.mask[p] : 1.f);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      float dh;
+      const float h = huber(om * (gain * A.image[c * HW + p] + bias - A.gt[c * HW + p]), A.huber_delta, dh);
+      acc += h * h;
+    }
+  }
+  const float t = block_sum(acc, s_red);
+  if (threadIdx.x == 0) A.partial[blockIdx.x] = t;
+}
+
+// loss = sqrt(sum partial); scalars[0] = loss, scalars[1] = 1/loss (0 if loss == 0)
+__global__ __launch_bounds__(kLossBlock) void k_track_loss_finish(mgs_tracking_loss_args A, int nblk) {
+  __shared__ float s_red[kLossBlock / 64];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += kLossBlock) acc += A.partial[i];
+  const float t = block_sum(acc, s_red);
+  if (threadIdx.x == 0) {
+    const float l = sqrtf(t);
+    A.scalars[0] = l;
+    A.scalars[1] = l > 0.f ? 1.f / l : 0.f;
+  }
+}
+
+// grad_image = gout/loss * h * h' * om * gain ; partial sums for d/da, d/db
+__global__ __launch_bounds__(kLossBlock) void k_track_loss_bwd(mgs_tracking_loss_args A) {
+  __shared__ float s_red[kLossBlock / 64];
+  const float a = A.exposure_a[0];
+  const float gain = fabsf(a) + A.exposure_eps, bias = A.exposure_b[0];
+  const float sgn = a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f);
+  const float k = A.grad_out[0] * A.scalars[1];
+  const size_t HW = (size_t)A.num_pixels;
+  float ga = 0.f, gb = 0.f;
+  for (size_t p = (size_t)blockIdx.x * kLossBlock + threadIdx.x; p < HW; p += (size_t)gridDim.x * kLossBlock) {
+    const float om = A.opacity[p] * (A.mask ? A.mask[p] : 1.f);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float im = A.image[c * HW + p];
+      float dh;
+      const float h = huber(om * (gain * im + bias - A.gt[c * HW + p]), A.huber_delta, dh);
+      const float gr = k * h * dh * om;       // dL/d(residual before opacity) * om
+      A.grad_image[c * HW + p] = gr * gain;
+      ga += gr * im;
+      gb += gr;
+    }
+  }
+  const float ta = block_sum(ga, s_red);
+  const float tb = block_sum(gb, s_red);
+  if (threadIdx.x == 0) {
+    A.partial[blockIdx.x] = ta * sgn;
+    A.partial[gridDim.x + blockIdx.x] = tb;
+  }
+}
+
+__global__ __launch_bounds__(kLossBlock) void k_track_loss_bwd_finish(mgs_tracking_loss_args A, int nblk) {
+  __shared__ float s_red[kLossBlock / 64];
+  float x = 0.f, y = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += kLossBlock) { x += A.partial[i]; y += A.partial[nblk + i]; }
+  const float ta = block_sum(x, s_red);
+  const float tb = block_sum(y, s_red);
+  if (threadIdx.x == 0) { A.grad_a[0] = ta; A.grad_b[0] = tb; }
+}
+
+// ---------------------------------------------------------------------------------
+// Damped least squares of the sketched LM step (utils/slam_frontend.py:672-697):
+//   x = argmin || [SJ; sqrt(lambda) I] x + [Sf; 0] ||   <=>   (SJ^T SJ + lambda I) x = -SJ^T Sf
+// with 8 unknowns [trans(3), rot(3), exposure_a, exposure_b], followed by TempCamera.step
+// (:49-53): T <- Exp(x[:6]) T, exposure += x[6:8].  One workgroup: fp64 row reduction,
+// 8x8 Cholesky by thread 0.  (torch.linalg.lstsq on this 1032x8 problem costs ~3.7 ms of
+// host-side solver setup per call.)
+__global__ __launch_bounds__(256) void k_lm_solve_step(mgs_lm_step_args A) {
+  __shared__ double s_red[4][44];
+  double acc[44];
+#pragma unroll
+  for (int i = 0; i < 44; i++) acc[i] = 0.0;
+  for (int r = threadIdx.x; r < A.rows; r += 256) {
+    float row[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) row[i] = A.SJ[(size_t)r * 8 + i];
+    const float f = A.Sf[r];
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+      for (int j = i; j < 8; j++) acc[k++] += (double)row[i] * (double)row[j];
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[36 + i] += (double)row[i] * (double)f;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 44; i++) {
+    double v = acc[i];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if (lane == 0) s_red[wave][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double H[8][8], g[8];
+  int k = 0;
+  for (int i = 0; i < 8; i++)
+    for (int j = i; j < 8; j++) {
+      const double v = s_red[0][k] + s_red[1][k] + s_red[2][k] + s_red[3][k];
+      H[i][j] = v; H[j][i] = v;
+      k++;
+    }
+  for (int i = 0; i < 8; i++) {
+    g[i] = -(s_red[0][36 + i] + s_red[1][36 + i] + s_red[2][36 + i] + s_red[3][36 + i]);
+    H[i][i] += (double)A.lambda;
+  }
+  // Cholesky H = L L^T (lambda > 0 makes H positive definite)
+  double L[8][8];
+  for (int i = 0; i < 8; i++)
+    for (int j = 0; j <= i; j++) {
+      double sum = H[i][j];
+      for (int q = 0; q < j; q++) sum -= L[i][q] * L[j][q];
+      L[i][j] = (i == j) ? sqrt(sum > 1e-300 ? sum : 1e-300) : sum / L[j][j];
+    }
+  double y[8], x[8];
+  for (int i = 0; i < 8; i++) {
+    double sum = g[i];
+    for (int q = 0; q < i; q++) sum -= L[i][q] * y[q];
+    y[i] = sum / L[i][i];
+  }
+  for (int i = 7; i >= 0; i--) {
+    double sum = y[i];
+    for (int q = i + 1; q < 8; q++) sum -= L[q][i] * x[q];
+    x[i] = sum / L[i][i];
+  }
+  for (int i = 0; i < 8; i++) A.x_out[i] = (float)x[i];
+  if (A.T) {
+    const float rho[3] = {(float)x[0], (float)x[1], (float)x[2]};
+    const float th[3] = {(float)x[3], (float)x[4], (float)x[5]};
+    float R[9], V[9];
+    so3_exp_V(th, R, V);
+    float t[3];
+    for (int i = 0; i < 3; i++) t[i] = V[3 * i] * rho[0] + V[3 * i + 1] * rho[1] + V[3 * i + 2] * rho[2];
+    float Tn[12];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 4; j++)
+        Tn[4 * i + j] = R[3 * i] * A.T[j] + R[3 * i + 1] * A.T[4 + j] + R[3 * i + 2] * A.T[8 + j] +
+                        (j == 3 ? t[i] : 0.f) * A.T[15];
+    for (int i = 0; i < 12; i++) A.T[i] = Tn[i];
+  }
+  if (A.exposure_a) A.exposure_a[0] += (float)x[6];
+  if (A.exposure_b) A.exposure_b[0] += (float)x[7];
+}
+
+static int loss_blocks(int64_t hw) {
+  const int64_t b = (hw + kLossBlock - 1) / kLossBlock;
+  return (int)(b < kLossBlocks ? (b < 1 ? 1 : b) : kLossBlocks);
+}
+
+}  // namespace mgs
+
+using namespace mgs;
+
+extern "C" {
+
+int32_t mgs_pose_adam_step(const mgs_pose_adam_args* a, void* stream) {
+  if (!a || !a->cam_rot_delta || !a->cam_trans_delta || !a->exp_avg || !a->exp_avg_sq || a->step < 1)
+    return MGS_ERR_BAD_ARGUMENT;
+  if ((a->grad_a && !a->exposure_a) || (a->grad_b && !a->exposure_b)) return MGS_ERR_BAD_ARGUMENT;
+  launch("pose_adam_update", k_pose_adam_update, dim3(1), dim3(64), (hipStream_t)stream, *a);
+  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+}
+
+int32_t mgs_lm_solve_step(const mgs_lm_step_args* a, void* stream) {
+  if (!a || !a->SJ || !a->Sf || !a->x_out || a->rows < 1 || !(a->lambda > 0.f)) return MGS_ERR_BAD_ARGUMENT;
+  launch("lm_solve_step", k_lm_solve_step, dim3(1), dim3(256), (hipStream_t)stream, *a);
+  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+}
+
+int32_t mgs_tracking_loss_partial_count(int64_t num_pixels) { return 2 * loss_blocks(num_pixels); }
+
+int32_t mgs_tracking_loss_forward(const mgs_tracking_loss_args* a, void* stream) {
+  if (!a || !a->image || !a->opacity || !a->gt || !a->exposure_a || !a->exposure_b || !a->partial ||
+      !a->scalars || a->num_pixels < 1)
+    return MGS_ERR_BAD_ARGUMENT;
+  const int nb = loss_blocks(a->num_pixels);
+  launch("track_loss_fwd", k_track_loss_fwd, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a);
+  launch("track_loss_finish", k_track_loss_finish, dim3(1), dim3(kLossBlock), (hipStream_t)stream, *a, nb);
+  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+}
+
+int32_t mgs_tracking_loss_backward(const mgs_tracking_loss_args* a, void* stream) {
+  if (!a || !a->image || !a->opacity || !a->gt || !a->exposure_a || !a->exposure_b || !a->partial ||
+      !a->scalars || !a->grad_out || !a->grad_image || !a->grad_a || !a->grad_b || a->num_pixels < 1)
+    return MGS_ERR_BAD_ARGUMENT;
+  const int nb = loss_blocks(a->num_pixels);
+  launch("track_loss_bwd", k_track_loss_bwd, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a);
+  launch("track_loss_bwd_fin", k_track_loss_bwd_finish, dim3(1), dim3(kLossBlock), (hipStream_t)stream, *a, nb);
+  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+}
+
+}  // extern "C"

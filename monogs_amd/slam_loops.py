@@ -115,6 +115,22 @@ def tracking_step_first_order(viewpoint, gaussians, pose_optimizer, background, 
     return loss.detach(), converged, render_pkg
 
 
+def tracking_step_first_order_fused(viewpoint, gaussians, fused_optimizer, background, pipe=Pipe,
+                                    config=DEFAULT_CONFIG):
+    """Same iteration as tracking_step_first_order with the loss and the optimiser step +
+    update_pose as fused HIP launches (monogs_amd/tracking_fused.py).  Returns the
+    convergence flag as a device tensor (no host sync inside)."""
+    from .tracking_fused import tracking_loss
+    render_pkg = render(viewpoint, gaussians, pipe, background)
+    rgn = config["Training"]["RGN"]
+    loss = tracking_loss(render_pkg["render"], render_pkg["opacity"], viewpoint,
+                         rgn["huber_delta"] if rgn["use_huber"] else 0.0)
+    fused_optimizer.zero_grad()
+    loss.backward()
+    converged = fused_optimizer.step()
+    return loss.detach(), converged, render_pkg
+
+
 def gen_forward_sketch_args(height, width, repeat_dim, stack_dim, sketch_dim, device,
                             generator: Optional[torch.Generator] = None):
     """CountSketch bookkeeping of slam_frontend.py:269-338: every repeat draws a random
@@ -148,7 +164,7 @@ def gen_forward_sketch_args(height, width, repeat_dim, stack_dim, sketch_dim, de
 
 def tracking_step_second_order(viewpoint, gaussians, background, lambda_, repeat_dim=1,
                                stack_dim=16, sketch_dim=64, pipe=Pipe, config=DEFAULT_CONFIG,
-                               generator=None):
+                               generator=None, fused_solve=False):
     """One sketched Levenberg-Marquardt iteration (slam_frontend.py:484-710): sketched
     render, bucket-summed residual Sf, `repeat_dim` backward passes harvesting the sketched
     Jacobian SJ[(repeat*stack*sketch), 8], damped least squares, left-multiplicative pose
@@ -176,6 +192,13 @@ def tracking_step_second_order(viewpoint, gaussians, background, lambda_, repeat
             p.grad = None
         weighted[i].backward(gradient=torch.ones_like(weighted[i]), retain_graph=True)
         SJ[i] = torch.cat((fsa["sketch_dtau"].grad, fsa["sketch_dexposure"].grad), dim=2)
+    if fused_solve:    # one HIP launch: normal equations + Cholesky + pose / exposure step
+        from .tracking_fused import lm_solve_step
+        with torch.no_grad():
+            SJ = SJ.reshape(-1, n)
+            Sf = Sf.flatten()
+            x = lm_solve_step(SJ, Sf, lambda_, viewpoint)
+        return weighted.detach().abs().sum(), x, SJ, Sf
     with torch.no_grad():
         SJ = SJ.reshape(-1, n)
         Sf = Sf.flatten()

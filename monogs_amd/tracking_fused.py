@@ -1,0 +1,133 @@
+"""Fused tracking-loop glue (HIP): the monocular tracking objective and the pose
+optimiser step + update_pose, each a couple of launches instead of ~100 PyTorch kernels.
+
+Semantics are those of the reference's PyTorch code (checked in tests against
+monogs_amd/losses.py and torch.optim.Adam + monogs_amd/pose.update_pose):
+  * loss     utils/slam_utils.py:188-205 (+ Huber :58-75, L2 norm slam_frontend.py:596-598)
+  * optimise utils/slam_frontend.py:364-392,606-615 and utils/pose_utils.py:88-98
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _cabi
+
+
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+class _TrackingLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, opacity, gt, mask, exposure_a, exposure_b, exposure_eps, huber_delta):
+        dev = image.device
+        if dev.type != "cuda":
+            raise RuntimeError("fused tracking loss runs on the GPU only; use monogs_amd.losses on CPU")
+        lib = _cabi.lib()
+        image_c = image.detach().float().contiguous()
+        opa_c = opacity.detach().float().contiguous()
+        gt_c = gt.detach().float().contiguous()
+        mask_c = None if mask is None else mask.detach().float().contiguous()
+        HW = int(image_c.shape[-1] * image_c.shape[-2])
+        partial = torch.empty(int(lib.mgs_tracking_loss_partial_count(HW)), dtype=torch.float32, device=dev)
+        scalars = torch.empty(2, dtype=torch.float32, device=dev)
+        a = _cabi.TrackingLossArgs()
+        a.image, a.opacity, a.gt = image_c.data_ptr(), opa_c.data_ptr(), gt_c.data_ptr()
+        a.mask = None if mask_c is None else mask_c.data_ptr()
+        a.exposure_a, a.exposure_b = exposure_a.data_ptr(), exposure_b.data_ptr()
+        a.exposure_eps, a.huber_delta, a.num_pixels = float(exposure_eps), float(huber_delta), HW
+        a.partial, a.scalars = partial.data_ptr(), scalars.data_ptr()
+        _cabi.check(lib.mgs_tracking_loss_forward(C.byref(a), _stream(dev)), "mgs_tracking_loss_forward")
+        ctx.save_for_backward(image_c, opa_c, gt_c, mask_c, exposure_a, exposure_b, partial, scalars)
+        ctx.consts = (float(exposure_eps), float(huber_delta), HW)
+        return scalars[0].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        image_c, opa_c, gt_c, mask_c, exposure_a, exposure_b, partial, scalars = ctx.saved_tensors
+        dev = image_c.device
+        lib = _cabi.lib()
+        eps, delta, HW = ctx.consts
+        go = grad_out.detach().float().reshape(1).contiguous()
+        g_img = torch.empty_like(image_c)
+        g_a = torch.empty(1, dtype=torch.float32, device=dev)
+        g_b = torch.empty(1, dtype=torch.float32, device=dev)
+        a = _cabi.TrackingLossArgs()
+        a.image, a.opacity, a.gt = image_c.data_ptr(), opa_c.data_ptr(), gt_c.data_ptr()
+        a.mask = None if mask_c is None else mask_c.data_ptr()
+        a.exposure_a, a.exposure_b = exposure_a.data_ptr(), exposure_b.data_ptr()
+        a.exposure_eps, a.huber_delta, a.num_pixels = eps, delta, HW
+        a.partial, a.scalars = partial.data_ptr(), scalars.data_ptr()
+        a.grad_out, a.grad_image = go.data_ptr(), g_img.data_ptr()
+        a.grad_a, a.grad_b = g_a.data_ptr(), g_b.data_ptr()
+        _cabi.check(lib.mgs_tracking_loss_backward(C.byref(a), _stream(dev)), "mgs_tracking_loss_backward")
+        return (g_img, None, None, None, g_a.reshape(exposure_a.shape), g_b.reshape(exposure_b.shape),
+                None, None)
+
+
+def tracking_loss(image, opacity, viewpoint, huber_delta=0.01):
+    """|| Huber( opacity * mask * ((|a|+eps) image + b - gt) ) ||_2 for `viewpoint`
+    (attributes original_image, rgb_pixel_mask_mapping, exposure_a/b/eps)."""
+    mask = viewpoint.rgb_pixel_mask_mapping
+    return _TrackingLoss.apply(image, opacity, viewpoint.original_image, mask, viewpoint.exposure_a,
+                               viewpoint.exposure_b, viewpoint.exposure_eps, huber_delta)
+
+
+class FusedPoseOptimizer:
+    """Adam on (cam_rot_delta, cam_trans_delta, exposure_a, exposure_b) + update_pose in ONE
+    launch.  `step()` returns a device int32 flag tensor (1 = converged): reading it is the
+    caller's (optional) host sync."""
+
+    def __init__(self, viewpoint, lr_rot=0.003, lr_trans=0.001, lr_a=0.02, lr_b=0.02,
+                 betas=(0.9, 0.999), eps=1e-8, converged_threshold=1e-4):
+        self.vp = viewpoint
+        dev = viewpoint.cam_rot_delta.device
+        self.exp_avg = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.converged = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.t = 0
+        self.hp = (lr_rot, lr_trans, lr_a, lr_b, betas[0], betas[1], eps, converged_threshold)
+
+    def zero_grad(self):
+        for p in (self.vp.cam_rot_delta, self.vp.cam_trans_delta, self.vp.exposure_a, self.vp.exposure_b):
+            p.grad = None
+
+    def step(self, update_pose=True):
+        vp = self.vp
+        dev = vp.cam_rot_delta.device
+        self.t += 1
+        a = _cabi.PoseAdamArgs()
+        a.cam_rot_delta, a.cam_trans_delta = vp.cam_rot_delta.data_ptr(), vp.cam_trans_delta.data_ptr()
+        a.exposure_a, a.exposure_b = vp.exposure_a.data_ptr(), vp.exposure_b.data_ptr()
+        g = [p.grad for p in (vp.cam_rot_delta, vp.cam_trans_delta, vp.exposure_a, vp.exposure_b)]
+        g = [None if x is None else x.contiguous() for x in g]
+        a.grad_rot, a.grad_trans, a.grad_a, a.grad_b = [None if x is None else x.data_ptr() for x in g]
+        a.exp_avg, a.exp_avg_sq = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
+        if update_pose:
+            assert vp.T.is_contiguous() and vp.T.dtype == torch.float32
+            a.T = vp.T.data_ptr()
+        a.converged = self.converged.data_ptr()
+        a.step = self.t
+        (a.lr_rot, a.lr_trans, a.lr_a, a.lr_b, a.beta1, a.beta2, a.eps, a.converged_threshold) = self.hp
+        _cabi.check(_cabi.lib().mgs_pose_adam_step(C.byref(a), _stream(dev)), "mgs_pose_adam_step")
+        return self.converged
+
+
+def lm_solve_step(SJ: torch.Tensor, Sf: torch.Tensor, lambda_: float, viewpoint=None) -> torch.Tensor:
+    """x = argmin ||[SJ; sqrt(lambda) I] x + [Sf; 0]|| (8 unknowns) in one launch; with
+    `viewpoint`, also T <- Exp(x[:6]) T and exposure += x[6:8] (slam_frontend.py:672-697)."""
+    dev = SJ.device
+    SJc = SJ.detach().float().reshape(-1, 8).contiguous()
+    Sfc = Sf.detach().float().reshape(-1).contiguous()
+    x = torch.empty(8, dtype=torch.float32, device=dev)
+    a = _cabi.LMStepArgs()
+    a.SJ, a.Sf, a.rows, a.lam = SJc.data_ptr(), Sfc.data_ptr(), int(SJc.shape[0]), float(lambda_)
+    if viewpoint is not None:
+        assert viewpoint.T.is_contiguous() and viewpoint.T.dtype == torch.float32
+        a.T = viewpoint.T.data_ptr()
+        a.exposure_a, a.exposure_b = viewpoint.exposure_a.data_ptr(), viewpoint.exposure_b.data_ptr()
+    a.x_out = x.data_ptr()
+    _cabi.check(_cabi.lib().mgs_lm_solve_step(C.byref(a), _stream(dev)), "mgs_lm_solve_step")
+    return x

@@ -573,3 +573,131 @@ def test_degenerate_inputs_do_not_fault(built):
         assert torch.isfinite(t).all()
     assert (radii[96:128] == 0).all()                   # z <= 0.2 is culled
     assert (L["m"].grad[:32] == 0).all()                # opacity 0 never reaches 1/255
+
+
+# ---------------------------------------------------------------------------------------
+# fused tracking-loop glue
+# ---------------------------------------------------------------------------------------
+def test_fused_tracking_loss_matches_torch_reference(built):
+    from monogs_amd import losses as Ls
+    from monogs_amd.tracking_fused import tracking_loss
+    dev = _dev()
+    g = torch.Generator().manual_seed(0)
+    H, W = 120, 160
+
+    class VP:
+        pass
+
+    for delta, a0 in ((0.01, 0.9), (0.0, -1.1)):
+        vp = VP()
+        vp.original_image = torch.rand(3, H, W, generator=g).to(dev)
+        vp.rgb_pixel_mask_mapping = (torch.rand(1, H, W, generator=g) > 0.2).to(dev)
+        vp.exposure_a = torch.tensor([a0], device=dev, requires_grad=True)
+        vp.exposure_b = torch.tensor([0.03], device=dev, requires_grad=True)
+        vp.exposure_eps = 1e-8
+        img = torch.rand(3, H, W, generator=g).to(dev).requires_grad_()
+        opa = torch.rand(1, H, W, generator=g).to(dev)
+        cfg = {"Training": {"monocular": True}}
+        res = Ls.get_loss_tracking_per_pixel(cfg, img, None, opa, vp)
+        if delta > 0:
+            res = Ls.HuberLoss.apply(res, delta)
+        ref = torch.norm(res.flatten(), p=2)
+        (2.5 * ref).backward()
+        want = (ref.item(), img.grad.clone(), vp.exposure_a.grad.clone(), vp.exposure_b.grad.clone())
+        img.grad = None
+        vp.exposure_a.grad = None
+        vp.exposure_b.grad = None
+        got = tracking_loss(img, opa, vp, delta)
+        (2.5 * got).backward()
+        assert abs(got.item() - want[0]) <= 1e-5 * want[0]
+        assert rel_err(img.grad, want[1]) < 1e-5
+        assert rel_err(vp.exposure_a.grad, want[2]) < 1e-4 and rel_err(vp.exposure_b.grad, want[3]) < 1e-4
+
+
+def test_fused_pose_optimizer_matches_adam_plus_update_pose(built):
+    from monogs_amd.pose import SE3_exp, update_pose
+    from monogs_amd.tracking_fused import FusedPoseOptimizer
+    dev = _dev()
+
+    class Cam:
+        pass
+
+    def make():
+        c = Cam()
+        c.T = SE3_exp(torch.tensor([0.1, 0.2, -0.1, 0.05, 0.0, 0.02])).to(dev).contiguous()
+        c.cam_rot_delta = torch.nn.Parameter(torch.zeros(3, device=dev))
+        c.cam_trans_delta = torch.nn.Parameter(torch.zeros(3, device=dev))
+        c.exposure_a = torch.nn.Parameter(torch.tensor([1.0], device=dev))
+        c.exposure_b = torch.nn.Parameter(torch.tensor([0.0], device=dev))
+        return c
+
+    ca, cb = make(), make()
+    opt = torch.optim.Adam([{"params": [ca.cam_rot_delta], "lr": 0.003}, {"params": [ca.cam_trans_delta], "lr": 0.001},
+                            {"params": [ca.exposure_a], "lr": 0.02}, {"params": [ca.exposure_b], "lr": 0.02}])
+    fused = FusedPoseOptimizer(cb)
+    g = torch.Generator().manual_seed(1)
+    for it in range(12):
+        grads = [torch.randn(3, generator=g) * 10 ** float(torch.randint(-4, 1, (1,), generator=g)),
+                 torch.randn(3, generator=g), torch.randn(1, generator=g), torch.randn(1, generator=g) * 1e-3]
+        if it == 11:
+            grads = [torch.zeros_like(x) for x in grads]
+        for c in (ca, cb):
+            for p, gr in zip((c.cam_rot_delta, c.cam_trans_delta, c.exposure_a, c.exposure_b), grads):
+                p.grad = gr.to(dev).clone()
+        opt.step()
+        conv_ref = update_pose(ca)
+        conv = fused.step()
+        assert torch.allclose(ca.T, cb.T, atol=2e-6), it
+        assert torch.allclose(ca.exposure_a, cb.exposure_a, atol=1e-6) and torch.allclose(ca.exposure_b, cb.exposure_b, atol=1e-6)
+        assert cb.cam_rot_delta.abs().sum() == 0 and cb.cam_trans_delta.abs().sum() == 0
+        assert bool(conv.item()) == conv_ref
+
+
+def test_fused_tracking_iteration_converges_like_the_reference_loop(built):
+    from monogs_amd.gaussian_renderer import render
+    from monogs_amd.pose import SE3_exp
+    from monogs_amd.slam_loops import Pipe, make_pose_optimizer, tracking_step_first_order, tracking_step_first_order_fused
+    from monogs_amd.tracking_fused import FusedPoseOptimizer
+    sc, gauss, view, dev = _loop_fixture()
+    bg = torch.zeros(3, device=dev)
+    with torch.no_grad():
+        target = render(view(1, torch.eye(4)), gauss, Pipe, bg)["render"].clone()
+    T0 = SE3_exp(torch.tensor([0.02, -0.015, 0.01, 0.004, -0.006, 0.003]))
+    va, vb = view(2, T0), view(3, T0)
+    for v in (va, vb):
+        v.original_image = target
+        v.rgb_pixel_mask_mapping = (target.sum(0) > 0.01).view(1, *target.shape[1:])
+    oa, ob = make_pose_optimizer(va), FusedPoseOptimizer(vb)
+    for _ in range(15):
+        la, _, _ = tracking_step_first_order(va, gauss, oa, bg)
+        lb, _, _ = tracking_step_first_order_fused(vb, gauss, ob, bg)
+    assert abs(la.item() - lb.item()) <= 1e-3 * abs(la.item())
+    assert torch.allclose(va.T, vb.T, atol=1e-4)
+
+
+def test_fused_lm_solve_matches_damped_lstsq(built):
+    import math
+    from monogs_amd.pose import SE3_exp
+    from monogs_amd.tracking_fused import lm_solve_step
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    for rows, lam in ((1024, 1e-3), (37, 0.5)):
+        SJ = torch.randn(rows, 8, generator=g) * torch.tensor([3.0, 2.0, 1.0, 5.0, 4.0, 6.0, 0.5, 0.2])
+        Sf = torch.randn(rows, generator=g)
+        A = torch.cat((SJ, torch.eye(8) * math.sqrt(lam)), 0).double()
+        b = torch.cat((Sf, torch.zeros(8)), 0).double()
+        want = torch.linalg.lstsq(A, -b).solution.float()
+
+        class Cam:
+            pass
+
+        c = Cam()
+        c.T = SE3_exp(torch.tensor([0.1, 0.2, -0.1, 0.05, 0.0, 0.02])).to(dev).contiguous()
+        T0 = c.T.clone().cpu()
+        c.exposure_a = torch.tensor([1.0], device=dev)
+        c.exposure_b = torch.tensor([0.0], device=dev)
+        x = lm_solve_step(SJ.to(dev), Sf.to(dev), lam, c).cpu()
+        assert torch.allclose(x, want, rtol=1e-4, atol=1e-6)
+        assert torch.allclose(c.T.cpu(), SE3_exp(want[:6]) @ T0, atol=1e-5)
+        assert abs(c.exposure_a.item() - (1.0 + want[6].item())) < 1e-5
+        assert abs(c.exposure_b.item() - want[7].item()) < 1e-5
