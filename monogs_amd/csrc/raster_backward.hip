@@ -14,6 +14,7 @@
 // sinks: gaussian_model.py:252-285,693-697, slam_frontend.py:365-378,606-611).
 #include "launch.h"
 #include "raster_kernels.h"
+#include "wave_reduce.h"
 
 namespace mgs {
 
@@ -188,9 +189,10 @@ __global__ __launch_bounds__(256) void k_scan_write(KP P, KB B) {
 // colour F) in front of every segment, so items are independent: no serial chain over a
 // tile's whole list, ~D/kSeg equal-sized items instead of T ragged ones.
 //
-// Front-to-back replay inside the segment.  With S = C_final - F_i (colour accumulated
-// behind splat i) the derivative of the pixel w.r.t. the splat's alpha is
-//   dL/dalpha_i = sum_ch dL/dC_ch * (T_i c_ch - S_ch / (1 - alpha_i)) - T_final bg.dL/dC / (1 - alpha_i)
+// Front-to-back replay inside the segment.  With S = (C_final + T_final bg) - F_i (colour
+// still to come behind splat i, background included) the derivative of the pixel w.r.t. the
+// splat's alpha is
+//   dL/dalpha_i = sum_ch dL/dC_ch * (T_i c_ch - S_ch / (1 - alpha_i))
 // and every screen-space gradient of the splat is a pixel sum of W = dL/dG * G or of the
 // blend weight w = alpha T times a monomial of (dx, dy) / the pixel's upstream gradient:
 //   S1 = sum W, Sx = sum W dx, Sy = sum W dy, Sxx, Sxy, Syy      (mean2D, conic, opacity)
@@ -223,10 +225,12 @@ __global__ __launch_bounds__(64) void k_blend_bwd(KP P, KB B) {
   const size_t HW = (size_t)P.W * P.H;
 
   // ---- stage the segment's records (2 per lane), remember slot + raw conic ---------
-  int slot[2] = {-1, -1};
-  float4 qa[2], qb[2];
+  constexpr int kStage = kSeg / 64;   // records staged per lane
+  int slot[kStage];
+  float4 qa[kStage], qb[kStage];
 #pragma unroll
-  for (int h = 0; h < 2; h++) {
+  for (int h = 0; h < kStage; h++) {
+    slot[h] = -1;
     const int jj = lane + 64 * h;
     if (jj < nb) {
       const int k = start + base + jj;
@@ -249,41 +253,45 @@ __global__ __launch_bounds__(64) void k_blend_bwd(KP P, KB B) {
   }
 
   // ---- per-pixel data: pixel q of this lane is tile pixel lane + 64 q --------------------
+  // State per pixel: T (transmittance in front of the next splat) and S = colour/depth still
+  // to come BEHIND the splats visited so far, background included:
+  //   S = (C_final + T_final * bg) - F,  F = prefix colour from the checkpoint.
+  // Keeping S instead of (C_final, F) saves 16 VGPRs and folds the background term of
+  // dL/dalpha into the same expression.
   int last[4];
   v2f gA0, gA1, gA2, gAd, gB0, gB1, gB2, gBd;        // dL/dC, dL/dD   (A: q=0,1  B: q=2,3)
-  v2f cA0, cA1, cA2, cAd, cB0, cB1, cB2, cBd;        // final colour (no background), depth
-  v2f TfA, TfB;                                        // -T_final * (bg . dL/dC)
+  v2f sA0, sA1, sA2, sAd, sB0, sB1, sB2, sBd;        // S
   v2f TA = {1.f, 1.f}, TB = {1.f, 1.f};
-  v2f fA0 = {0.f, 0.f}, fA1 = fA0, fA2 = fA0, fAd = fA0, fB0 = fA0, fB1 = fA0, fB2 = fA0, fBd = fA0;
   const float bg0 = P.bg[0], bg1 = P.bg[1], bg2 = P.bg[2];
   const float* ck = (seg > 0) ? P.ckpt + (size_t)item * (5 * 256) : nullptr;
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const int py = pyb + 4 * q;
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f, gd = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, cd = 0.f, tf = 0.f;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, gd = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, cd = 0.f;
     int l = 0;
     if (px < P.W && py < P.H) {
       const size_t pix = (size_t)py * P.W + px;
       l = P.n_contrib[pix];
       g0 = B.grad_color[pix]; g1 = B.grad_color[HW + pix]; g2 = B.grad_color[2 * HW + pix];
       if (B.grad_depth) gd = B.grad_depth[pix];
-      c0 = P.final_C[pix]; c1 = P.final_C[HW + pix]; c2 = P.final_C[2 * HW + pix];
+      const float tf = P.final_T[pix];
+      c0 = P.final_C[pix] + tf * bg0; c1 = P.final_C[HW + pix] + tf * bg1;
+      c2 = P.final_C[2 * HW + pix] + tf * bg2;
       cd = P.final_C[3 * HW + pix];
-      tf = -P.final_T[pix] * (bg0 * g0 + bg1 * g1 + bg2 * g2);
     }
     last[q] = l;
-    float t = 1.f, f0 = 0.f, f1 = 0.f, f2 = 0.f, fd = 0.f;
+    float t = 1.f;
     if (ck) {
       const int p = lane + 64 * q;
-      t = ck[p]; f0 = ck[256 + p]; f1 = ck[512 + p]; f2 = ck[768 + p]; fd = ck[1024 + p];
+      t = ck[p]; c0 -= ck[256 + p]; c1 -= ck[512 + p]; c2 -= ck[768 + p]; cd -= ck[1024 + p];
     }
     const int e = q & 1;
     if (q < 2) {
-      gA0[e] = g0; gA1[e] = g1; gA2[e] = g2; gAd[e] = gd; cA0[e] = c0; cA1[e] = c1; cA2[e] = c2;
-      cAd[e] = cd; TfA[e] = tf; TA[e] = t; fA0[e] = f0; fA1[e] = f1; fA2[e] = f2; fAd[e] = fd;
+      gA0[e] = g0; gA1[e] = g1; gA2[e] = g2; gAd[e] = gd; sA0[e] = c0; sA1[e] = c1; sA2[e] = c2;
+      sAd[e] = cd; TA[e] = t;
     } else {
-      gB0[e] = g0; gB1[e] = g1; gB2[e] = g2; gBd[e] = gd; cB0[e] = c0; cB1[e] = c1; cB2[e] = c2;
-      cBd[e] = cd; TfB[e] = tf; TB[e] = t; fB0[e] = f0; fB1[e] = f1; fB2[e] = f2; fBd[e] = fd;
+      gB0[e] = g0; gB1[e] = g1; gB2[e] = g2; gBd[e] = gd; sB0[e] = c0; sB1[e] = c1; sB2[e] = c2;
+      sBd[e] = cd; TB[e] = t;
     }
   }
   // does any pixel of the tile reach this segment?
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(64) void k_blend_bwd(KP P, KB B) {
   for (int off = 32; off > 0; off >>= 1) ml = max(ml, __shfl_xor(ml, off));
   if (base >= ml) {
 #pragma unroll
-    for (int h = 0; h < 2; h++)
+    for (int h = 0; h < kStage; h++)
       if (slot[h] >= 0) {
         float4* dst = B.pair_grad + (size_t)slot[h] * 3;
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -305,6 +313,11 @@ __global__ __launch_bounds__(64) void k_blend_bwd(KP P, KB B) {
   v2f JA[6], JB[6];   // sketch mode: per-pixel pose-Jacobian rows of this segment
 #pragma unroll
   for (int t = 0; t < 6; t++) { JA[t] = v2f{0.f, 0.f}; JB[t] = v2f{0.f, 0.f}; }
+  // reduce-scatter bookkeeping (wave_reduce.h): which of the ten sums this lane ends up with
+  const unsigned long long b3mask = __ballot((lane & 8) != 0);
+  const bool wextra = lane == 31 || lane == 63;
+  const int wofs = wextra ? (lane == 31 ? 8 : 9)
+                          : ((lane & 7) == 0 ? ((lane >> 5) & 1) + 2 * ((lane >> 4) & 1) + 4 * ((lane >> 3) & 1) : -1);
   const float fpx = (float)px;
   const v2f fpyA = {(float)pyb, (float)(pyb + 4)}, fpyB = {(float)(pyb + 8), (float)(pyb + 12)};
   float4 u = s_r0[0], v = s_r1[0];
@@ -331,17 +344,15 @@ __global__ __launch_bounds__(64) void k_blend_bwd(KP P, KB B) {
       const v2f aeA = v2f{k0 ? alA.x : 0.f, k1 ? alA.y : 0.f};
       const v2f aeB = v2f{k2 ? alB.x : 0.f, k3 ? alB.y : 0.f};
       const v2f wA = aeA * TA, wB = aeB * TB;
-      fA0 += v.w * wA; fA1 += cgb.x * wA; fA2 += cgb.y * wA; fAd += v.z * wA;
-      fB0 += v.w * wB; fB1 += cgb.x * wB; fB2 += cgb.y * wB; fBd += v.z * wB;
+      sA0 -= v.w * wA; sA1 -= cgb.x * wA; sA2 -= cgb.y * wA; sAd -= v.z * wA;
+      sB0 -= v.w * wB; sB1 -= cgb.x * wB; sB2 -= cgb.y * wB; sBd -= v.z * wB;
       const v2f omA = 1.f - aeA, omB = 1.f - aeB;
       const v2f roA = v2f{__builtin_amdgcn_rcpf(omA.x), __builtin_amdgcn_rcpf(omA.y)};
       const v2f roB = v2f{__builtin_amdgcn_rcpf(omB.x), __builtin_amdgcn_rcpf(omB.y)};
-      v2f dA = gA0 * (v.w * TA - (cA0 - fA0) * roA) + gA1 * (cgb.x * TA - (cA1 - fA1) * roA) +
-               gA2 * (cgb.y * TA - (cA2 - fA2) * roA) + gAd * (v.z * TA - (cAd - fAd) * roA) +
-               TfA * roA;
-      v2f dB = gB0 * (v.w * TB - (cB0 - fB0) * roB) + gB1 * (cgb.x * TB - (cB1 - fB1) * roB) +
-               gB2 * (cgb.y * TB - (cB2 - fB2) * roB) + gBd * (v.z * TB - (cBd - fBd) * roB) +
-               TfB * roB;
+      const v2f dA = gA0 * (v.w * TA - sA0 * roA) + gA1 * (cgb.x * TA - sA1 * roA) +
+                     gA2 * (cgb.y * TA - sA2 * roA) + gAd * (v.z * TA - sAd * roA);
+      const v2f dB = gB0 * (v.w * TB - sB0 * roB) + gB1 * (cgb.x * TB - sB1 * roB) +
+                     gB2 * (cgb.y * TB - sB2 * roB) + gBd * (v.z * TB - sBd * roB);
       TA *= omA; TB *= omB;
       v2f WA = arA * dA, WB = arB * dB;
       WA = v2f{k0 ? WA.x : 0.f, k1 ? WA.y : 0.f};
@@ -371,12 +382,9 @@ __global__ __launch_bounds__(64) void k_blend_bwd(KP P, KB B) {
       r[0] = Ws; r[1] = Ws * dx; r[2] = Sy; r[3] = r[1] * dx; r[4] = Sy * dx;
       r[5] = WyyA.x + WyyA.y;
       r[6] = r6.x + r6.y; r[7] = r7.x + r7.y; r[8] = r8.x + r8.y; r[9] = r9.x + r9.y;
-      wave_sum10_to_lane63(r);
-      if (lane == 63) {
-        s_out[j][0] = make_float4(r[0], r[1], r[2], r[3]);
-        s_out[j][1] = make_float4(r[4], r[5], r[6], r[7]);
-        *reinterpret_cast<float2*>(&s_out[j][2]) = make_float2(r[8], r[9]);
-      }
+      float mres, eres;
+      wave_sum10_scatter(r, b3mask, mres, eres);
+      if (wofs >= 0) reinterpret_cast<float*>(&s_out[j][0])[wofs] = wextra ? eres : mres;
     }
     u = un; v = vn; cgb = cn;
   }
@@ -398,7 +406,7 @@ __global__ __launch_bounds__(64) void k_blend_bwd(KP P, KB B) {
   }
   __syncthreads();
 #pragma unroll
-  for (int h = 0; h < 2; h++) {
+  for (int h = 0; h < kStage; h++) {
     if (slot[h] >= 0) {
       const int jj = lane + 64 * h;
       const float4 p0 = s_out[jj][0], p1 = s_out[jj][1], p2 = s_out[jj][2];

@@ -392,12 +392,12 @@ __global__ __launch_bounds__(256) void k_tile_sort(KP P) {
 constexpr float kLog2e = 1.4426950408889634f;
 typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int kFwdThreads = 128;
-static_assert(kFwdThreads == kSeg, "one staged record per thread");
+static_assert(kFwdThreads == kFwdBatch && kFwdBatch == 2 * kSeg, "one staged record per thread, two segments per batch");
 
 __global__ __launch_bounds__(kFwdThreads) void k_blend_fwd(KP P) {
-  __shared__ float4 s_r0[kSeg], s_r1[kSeg];
-  __shared__ float2 s_r2[kSeg];
-  __shared__ unsigned int s_id[kSeg];
+  __shared__ float4 s_r0[kFwdBatch], s_r1[kFwdBatch];
+  __shared__ float2 s_r2[kFwdBatch];
+  __shared__ unsigned int s_id[kFwdBatch];
   const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int tx = tile % P.grid_x, ty = tile / P.grid_x;
   const int px = tx * kTile + (tid & 15);
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(kFwdThreads) void k_blend_fwd(KP P) {
   int last0 = 0, last1 = 0;
   const float fpx = (float)px;
   const v2f fpy = {(float)py0, (float)py1};
-  for (int base = 0; base < n; base += kSeg) {
+  for (int base = 0; base < n; base += kFwdBatch) {
     if (__syncthreads_count(live.x + live.y == 0.f) == kFwdThreads) break;
     const int k = start + base + tid;
     if (base + tid < n) {
@@ -428,19 +428,8 @@ __global__ __launch_bounds__(kFwdThreads) void k_blend_fwd(KP P) {
       s_r2[tid] = make_float2(c.y, c.z);
       s_id[tid] = id;
     }
-    if (base > 0) {   // checkpoint: state in front of this segment
-      const int sg = seg0 + base / kSeg;
-      if (sg < P.max_segs) {
-        float* ck = P.ckpt + (size_t)sg * (5 * 256);
-        ck[tid] = T.x; ck[128 + tid] = T.y;
-        ck[256 + tid] = C0.x; ck[384 + tid] = C0.y;
-        ck[512 + tid] = C1.x; ck[640 + tid] = C1.y;
-        ck[768 + tid] = C2.x; ck[896 + tid] = C2.y;
-        ck[1024 + tid] = D.x; ck[1152 + tid] = D.y;
-      }
-    }
     __syncthreads();
-    const int nb = min(kSeg, n - base);
+    const int nb = min(kFwdBatch, n - base);
     // n_touched of splat j of this batch accumulates in lane (j & 63), register j >> 6
     int tc0 = 0, tc1 = 0;
     auto blend_one = [&](const float4& u, const float4& v, const float2& cgb, int j, int& tc) {
@@ -471,6 +460,17 @@ __global__ __launch_bounds__(kFwdThreads) void k_blend_fwd(KP P) {
     for (int h = 0; h < 2; h++) {
       const int jlo = 64 * h, jhi = min(nb, jlo + 64);
       int tc = 0;
+      if (jlo < jhi && base + jlo > 0) {   // checkpoint: state in front of this segment
+        const int sg = seg0 + (base + jlo) / kSeg;
+        if (sg < P.max_segs) {
+          float* ck = P.ckpt + (size_t)sg * (5 * 256);
+          ck[tid] = T.x; ck[128 + tid] = T.y;
+          ck[256 + tid] = C0.x; ck[384 + tid] = C0.y;
+          ck[512 + tid] = C1.x; ck[640 + tid] = C1.y;
+          ck[768 + tid] = C2.x; ck[896 + tid] = C2.y;
+          ck[1024 + tid] = D.x; ck[1152 + tid] = D.y;
+        }
+      }
       if (jlo < jhi) {
         // two records in flight in two register sets: the LDS reads of the next splat are
         // issued before the current one is evaluated, without register-to-register moves
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(kFwdThreads) void k_blend_fwd(KP P) {
           const float4 ub = s_r0[j + 1], vb = s_r1[j + 1];
           const float2 cb = s_r2[j + 1];
           blend_one(ua, va, ca, j, tc);
-          const int j2 = min(j + 2, kSeg - 1);
+          const int j2 = min(j + 2, kFwdBatch - 1);
           ua = s_r0[j2]; va = s_r1[j2]; ca = s_r2[j2];
           blend_one(ub, vb, cb, j + 1, tc);
         }

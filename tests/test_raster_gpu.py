@@ -701,3 +701,15 @@ def test_fused_lm_solve_matches_damped_lstsq(built):
         assert torch.allclose(c.T.cpu(), SE3_exp(want[:6]) @ T0, atol=1e-5)
         assert abs(c.exposure_a.item() - (1.0 + want[6].item())) < 1e-5
         assert abs(c.exposure_b.item() - want[7].item()) < 1e-5
+
+
+def test_wave_reduce_scatter_unit(built, tmp_path):
+    """Kernel-level unit test of csrc/wave_reduce.h (permlane32/16 swap + DPP tree)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "test_wave_reduce")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-w",
+                           os.path.join(root, "tests", "hip", "test_wave_reduce.hip"), "-o", exe])
+    out = subprocess.run([exe], stdout=subprocess.PIPE, text=True, timeout=60)
+    assert out.returncode == 0 and "PASS" in out.stdout, out.stdout
