@@ -382,44 +382,51 @@ __global__ __launch_bounds__(256) void k_tile_sort(KP P) {
 }
 
 // ---------------------------------------------------------------------------------
-// Front-to-back blend: 128 threads (2 waves) = one 16x16 tile, TWO pixels per lane (rows y
-// and y+8 of one column: dx is shared, the pair's fp32 work packs into v_pk_*).  The
-// tile's sorted splat list is staged through LDS kSeg records at a time (all lanes read
-// the same record -> LDS broadcast); the staging thread pre-multiplies the conic by
-// -0.5*log2(e) so a pixel evaluation is a few FMAs + one v_exp_f32.  At every segment
-// boundary the per-pixel blend state (T, C, D) is checkpointed so that the backward can
-// process segments independently.
+// Front-to-back blend.  256 threads = one 16x16 tile; wave w owns the 8x8 QUADRANT
+// (w & 1, w >> 1) of the tile, one pixel per lane.  The tile's sorted splat list is staged
+// through LDS 256 records at a time; the staging thread pre-multiplies the conic by
+// -0.5*log2(e) (a pixel evaluation is a few FMAs + one v_exp_f32) and tests which of the
+// four quadrants its splat can reach at all (same closed-form bound as the tile culling,
+// on the 8x8 pixel box).  Each wave then walks only the splats whose bit is set for its
+// quadrant (ballot mask, scalar bit scan): for splats of a few pixels' extent about half
+// of the (wave, splat) evaluations disappear, and a tile's serial chain is split over four
+// independent waves instead of two.  Skipping is exact: a skipped splat has alpha < 1/255
+// on all 64 pixels.  Every kSeg splats the per-pixel blend state (T, C, D) is
+// checkpointed for the segment-parallel backward.
 constexpr float kLog2e = 1.4426950408889634f;
-typedef float v2f __attribute__((ext_vector_type(2)));
-constexpr int kFwdThreads = 128;
-static_assert(kFwdThreads == kFwdBatch && kFwdBatch == 2 * kSeg, "one staged record per thread, two segments per batch");
+constexpr int kFwdThreads = 256;
+constexpr int kFwdStage = 256;     // records staged per batch
+static_assert(kFwdStage % kSeg == 0 && kSeg == 64, "a batch is a whole number of 64-splat segments");
 
 __global__ __launch_bounds__(kFwdThreads) void k_blend_fwd(KP P) {
-  __shared__ float4 s_r0[kFwdBatch], s_r1[kFwdBatch];
-  __shared__ float2 s_r2[kFwdBatch];
-  __shared__ unsigned int s_id[kFwdBatch];
-  const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  __shared__ float4 s_r0[kFwdStage], s_r1[kFwdStage];
+  __shared__ float2 s_r2[kFwdStage];
+  __shared__ unsigned int s_id[kFwdStage];
+  __shared__ unsigned int s_mask[kFwdStage];
+  __shared__ int s_cnt[kFwdStage];
+  const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tx = tile % P.grid_x, ty = tile / P.grid_x;
-  const int px = tx * kTile + (tid & 15);
-  const int py0 = ty * kTile + (tid >> 4), py1 = py0 + 8;
-  const bool in0 = px < P.W && py0 < P.H, in1 = px < P.W && py1 < P.H;
+  const int qx0 = tx * kTile + 8 * (wave & 1), qy0 = ty * kTile + 8 * (wave >> 1);
+  const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+  const int ptile = (py - ty * kTile) * kTile + (px - tx * kTile);     // pixel index in the tile
+  const bool inside = px < P.W && py < P.H;
   int start = P.tile_offset[tile], end = P.tile_offset[tile + 1];
   start = min(start, P.cap); end = min(end, P.cap);
   const int n = end - start;
   const int seg0 = P.seg_offset[tile];
-  // Per-pixel state lives in VGPRs as floats (live = 1 until the pixel saturates or if it
-  // is outside the image): boolean loop-carried state would be kept as SGPR lane masks and
-  // costs three scalar instructions per mask and iteration.
-  v2f live = {in0 ? 1.f : 0.f, in1 ? 1.f : 0.f};
-  v2f T = {1.f, 1.f}, C0 = {0.f, 0.f}, C1 = {0.f, 0.f}, C2 = {0.f, 0.f}, D = {0.f, 0.f};
-  int last0 = 0, last1 = 0;
-  const float fpx = (float)px;
-  const v2f fpy = {(float)py0, (float)py1};
-  for (int base = 0; base < n; base += kFwdBatch) {
-    if (__syncthreads_count(live.x + live.y == 0.f) == kFwdThreads) break;
-    const int k = start + base + tid;
-    if (base + tid < n) {
-      const unsigned int id = (unsigned int)P.keys[k];
+  // quadrant boxes (pixel centres, clipped to the image) for the staging thread's test
+  const float bx0 = (float)(tx * kTile), by0 = (float)(ty * kTile);
+  const float Wm = (float)(P.W - 1), Hm = (float)(P.H - 1);
+  float live = inside ? 1.f : 0.f;
+  float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
+  int last = 0;
+  const float fpx = (float)px, fpy = (float)py;
+  for (int base = 0; base < n; base += kFwdStage) {
+    if (__syncthreads_count(live == 0.f) == kFwdThreads) break;
+    const int nb = min(kFwdStage, n - base);
+    unsigned int mask4 = 0;
+    if (tid < nb) {
+      const unsigned int id = (unsigned int)P.keys[start + base + tid];
       const float4* src = reinterpret_cast<const float4*>(P.rec + id);
       const float4 a = src[0], b = src[1], c = src[2];
       // (x, y, A', B') (C', opacity, depth, r) (g, b)
@@ -427,89 +434,73 @@ __global__ __launch_bounds__(kFwdThreads) void k_blend_fwd(KP P) {
       s_r1[tid] = make_float4(-0.5f * kLog2e * b.z, a.w, a.z, c.x);
       s_r2[tid] = make_float2(c.y, c.z);
       s_id[tid] = id;
+      const float qmax = splat_qmax(a.w);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const float x0 = bx0 + 8.f * (q & 1), y0 = by0 + 8.f * (q >> 1);
+        if (x0 <= Wm && y0 <= Hm &&
+            box_reachable(a.x, a.y, b.x, b.y, b.z, qmax, x0, y0, fminf(x0 + 7.f, Wm), fminf(y0 + 7.f, Hm)))
+          mask4 |= 1u << q;
+      }
+    }
+    s_mask[tid] = mask4;
+    s_cnt[tid] = 0;
+    __syncthreads();
+    for (int cb = 0; cb < nb; cb += kSeg) {
+      if (base + cb > 0) {   // checkpoint: state in front of this segment
+        const int sg = seg0 + (base + cb) / kSeg;
+        if (sg < P.max_segs) {
+          float* ck = P.ckpt + (size_t)sg * (5 * 256) + ptile;
+          ck[0] = T; ck[256] = C0; ck[512] = C1; ck[768] = C2; ck[1024] = D;
+        }
+      }
+      if (__builtin_amdgcn_ballot_w64(live != 0.f) == 0ull) continue;   // quadrant saturated
+      unsigned long long m = __builtin_amdgcn_ballot_w64(((s_mask[cb + lane] >> wave) & 1u) != 0);
+      if (m == 0ull) continue;
+      int j = cb + __builtin_ctzll(m);
+      float4 u = s_r0[j], v = s_r1[j];
+      float2 cgb = s_r2[j];
+      while (true) {
+        m &= m - 1ull;
+        const int jn = m ? cb + __builtin_ctzll(m) : j;
+        const float4 un = s_r0[jn], vn = s_r1[jn];     // prefetch the next splat of this quadrant
+        const float2 cn = s_r2[jn];
+        const float dx = u.x - fpx, dy = u.y - fpy;
+        const float pw = dx * (u.z * dx + u.w * dy) + v.x * dy * dy;
+        const float araw = v.y * __builtin_amdgcn_exp2f(pw);
+        float a = fminf(kAlphaMax, araw);
+        a = ((pw <= 0.f && a >= kAlphaMin) ? a : 0.f) * live;
+        const float test_T = T - a * T;
+        // T >= kTStop is invariant, so test_T < kTStop implies a > 0: the pixel saturates
+        // here, this splat is NOT blended and nothing after it is.
+        const bool stop = test_T < kTStop;
+        live = stop ? 0.f : live;
+        a = stop ? 0.f : a;
+        const float w = a * T;
+        C0 += v.w * w; C1 += cgb.x * w; C2 += cgb.y * w; D += v.z * w;
+        T = stop ? T : test_T;
+        last = a > 0.f ? (base + j + 1) : last;
+        const unsigned long long tm = __builtin_amdgcn_ballot_w64(a > 0.f && test_T > kTouchT);
+        if (tm != 0ull && lane == 0) atomicAdd(&s_cnt[j], __popcll(tm));
+        if (m == 0ull) break;
+        j = jn; u = un; v = vn; cgb = cn;
+      }
     }
     __syncthreads();
-    const int nb = min(kFwdBatch, n - base);
-    // n_touched of splat j of this batch accumulates in lane (j & 63), register j >> 6
-    int tc0 = 0, tc1 = 0;
-    auto blend_one = [&](const float4& u, const float4& v, const float2& cgb, int j, int& tc) {
-      const float dx = u.x - fpx;
-      const v2f dy = v2f{u.y, u.y} - fpy;
-      const v2f pw = dx * (u.z * dx + u.w * dy) + v.x * dy * dy;
-      const v2f araw = v.y * v2f{__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
-      v2f a = v2f{fminf(kAlphaMax, araw.x), fminf(kAlphaMax, araw.y)};
-      a = v2f{(pw.x <= 0.f && a.x >= kAlphaMin) ? a.x : 0.f,
-              (pw.y <= 0.f && a.y >= kAlphaMin) ? a.y : 0.f} * live;
-      const v2f test_T = T - a * T;
-      // T >= kTStop is invariant, so test_T < kTStop implies a > 0: the pixel saturates
-      // here, this splat is NOT blended and nothing after it is.
-      const bool stop0 = test_T.x < kTStop, stop1 = test_T.y < kTStop;
-      live = v2f{stop0 ? 0.f : live.x, stop1 ? 0.f : live.y};
-      a = v2f{stop0 ? 0.f : a.x, stop1 ? 0.f : a.y};
-      const v2f w = a * T;
-      C0 += v.w * w; C1 += cgb.x * w; C2 += cgb.y * w; D += v.z * w;
-      T = v2f{stop0 ? T.x : test_T.x, stop1 ? T.y : test_T.y};
-      const int idx1 = base + j + 1;
-      last0 = a.x > 0.f ? idx1 : last0;
-      last1 = a.y > 0.f ? idx1 : last1;
-      const int cnt = __popcll(__builtin_amdgcn_ballot_w64(a.x > 0.f && test_T.x > kTouchT)) +
-                      __popcll(__builtin_amdgcn_ballot_w64(a.y > 0.f && test_T.y > kTouchT));
-      tc = (lane == (j & 63)) ? cnt : tc;   // lane (j & 63) keeps splat j's count
-    };
-#pragma unroll 1
-    for (int h = 0; h < 2; h++) {
-      const int jlo = 64 * h, jhi = min(nb, jlo + 64);
-      int tc = 0;
-      if (jlo < jhi && base + jlo > 0) {   // checkpoint: state in front of this segment
-        const int sg = seg0 + (base + jlo) / kSeg;
-        if (sg < P.max_segs) {
-          float* ck = P.ckpt + (size_t)sg * (5 * 256);
-          ck[tid] = T.x; ck[128 + tid] = T.y;
-          ck[256 + tid] = C0.x; ck[384 + tid] = C0.y;
-          ck[512 + tid] = C1.x; ck[640 + tid] = C1.y;
-          ck[768 + tid] = C2.x; ck[896 + tid] = C2.y;
-          ck[1024 + tid] = D.x; ck[1152 + tid] = D.y;
-        }
-      }
-      if (jlo < jhi) {
-        // two records in flight in two register sets: the LDS reads of the next splat are
-        // issued before the current one is evaluated, without register-to-register moves
-        float4 ua = s_r0[jlo], va = s_r1[jlo];
-        float2 ca = s_r2[jlo];
-        int j = jlo;
-        for (; j + 1 < jhi; j += 2) {
-          const float4 ub = s_r0[j + 1], vb = s_r1[j + 1];
-          const float2 cb = s_r2[j + 1];
-          blend_one(ua, va, ca, j, tc);
-          const int j2 = min(j + 2, kFwdBatch - 1);
-          ua = s_r0[j2]; va = s_r1[j2]; ca = s_r2[j2];
-          blend_one(ub, vb, cb, j + 1, tc);
-        }
-        if (j < jhi) blend_one(ua, va, ca, j, tc);
-      }
-      if (h == 0) tc0 = tc; else tc1 = tc;
-      if (jhi >= nb) break;
-    }
-    if (tc0 > 0) atomicAdd(&P.n_touched[s_id[lane]], tc0);
-    if (tc1 > 0) atomicAdd(&P.n_touched[s_id[lane + 64]], tc1);
+    if (tid < nb && s_cnt[tid] > 0) atomicAdd(&P.n_touched[s_id[tid]], s_cnt[tid]);
   }
-  const size_t HW = (size_t)P.W * P.H;
-  const float bg0 = P.bg[0], bg1 = P.bg[1], bg2 = P.bg[2];
-#pragma unroll
-  for (int q = 0; q < 2; q++) {
-    if (q ? in1 : in0) {
-      const size_t pix = (size_t)(q ? py1 : py0) * P.W + px;
-      const float t = T[q];
-      P.final_T[pix] = t;
-      P.n_contrib[pix] = q ? last1 : last0;
-      P.final_C[pix] = C0[q]; P.final_C[HW + pix] = C1[q];
-      P.final_C[2 * HW + pix] = C2[q]; P.final_C[3 * HW + pix] = D[q];
-      P.out_color[pix] = C0[q] + t * bg0;
-      P.out_color[HW + pix] = C1[q] + t * bg1;
-      P.out_color[2 * HW + pix] = C2[q] + t * bg2;
-      P.out_depth[pix] = D[q];
-      P.out_opacity[pix] = 1.f - t;
-    }
+  if (inside) {
+    const size_t HW = (size_t)P.W * P.H;
+    const size_t pix = (size_t)py * P.W + px;
+    P.final_T[pix] = T;
+    P.n_contrib[pix] = last;
+    P.final_C[pix] = C0; P.final_C[HW + pix] = C1;
+    P.final_C[2 * HW + pix] = C2; P.final_C[3 * HW + pix] = D;
+    P.out_color[pix] = C0 + T * P.bg[0];
+    P.out_color[HW + pix] = C1 + T * P.bg[1];
+    P.out_color[2 * HW + pix] = C2 + T * P.bg[2];
+    P.out_depth[pix] = D;
+    P.out_opacity[pix] = 1.f - T;
   }
 }
 

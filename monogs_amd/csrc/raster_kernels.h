@@ -67,7 +67,6 @@ struct Layout {
 constexpr int kScanBlock = 2048;   // elements per block in the pair_base scan
 constexpr int kPreBlock = 256;
 constexpr int kSeg = 64;            // splats per blend segment (checkpoint interval)
-constexpr int kFwdBatch = 128;      // splats staged per forward batch (= forward threads)
 constexpr int kBinBlocks = 512;    // workgroups of the LDS-privatised binning passes
 constexpr int kBinThreads = 1024;
 constexpr int kBinMaxTilesLds = 12288;   // T above this falls back to global atomics

@@ -249,12 +249,10 @@ MGS_HD bool project_gaussian(const Camera& cam, const float p[3], const float* s
 // slack covers fp32 rounding of the per-pixel evaluation in the blend kernels.
 MGS_HD float splat_qmax(float opacity) { return 2.0f * logf(255.0f * opacity); }
 
-MGS_HD bool tile_reachable(float x, float y, float A, float B, float C, float qmax, int tx,
-                           int ty, int W, int H) {
+// Pixel-centre box [x0,x1] x [y0,y1] (inclusive, already clipped to the image).
+MGS_HD bool box_reachable(float x, float y, float A, float B, float C, float qmax, float x0,
+                          float y0, float x1, float y1) {
   if (!(qmax >= 0.f)) return false;  // opacity < 1/255 (or NaN): contributes nowhere
-  const float x0 = (float)(tx * kTile), y0 = (float)(ty * kTile);
-  const float x1 = fminf(x0 + (kTile - 1), (float)(W - 1));
-  const float y1 = fminf(y0 + (kTile - 1), (float)(H - 1));
   // d = mean - pixel  =>  dx in [x-x1, x-x0]
   const float lx = x - x1, hx = x - x0, ly = y - y1, hy = y - y0;
   if (lx <= 0.f && hx >= 0.f && ly <= 0.f && hy >= 0.f) return true;
@@ -276,6 +274,13 @@ MGS_HD bool tile_reachable(float x, float y, float A, float B, float C, float qm
   const float dm2 = fmaxf(lx * lx, hx * hx) + fmaxf(ly * ly, hy * hy);
   const float slack = 0.01f * qmax + 0.02f + 4e-6f * (A + C) * dm2;
   return !(qmin > qmax + slack);   // NaN-safe: keep the pair
+}
+
+MGS_HD bool tile_reachable(float x, float y, float A, float B, float C, float qmax, int tx,
+                           int ty, int W, int H) {
+  const float x0 = (float)(tx * kTile), y0 = (float)(ty * kTile);
+  return box_reachable(x, y, A, B, C, qmax, x0, y0, fminf(x0 + (kTile - 1), (float)(W - 1)),
+                       fminf(y0 + (kTile - 1), (float)(H - 1)));
 }
 
 // ------------------------------------------------------------------------- //
