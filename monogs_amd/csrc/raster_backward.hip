@@ -118,68 +118,11 @@ __device__ __forceinline__ void wave_sum10_to_lane63(float (&r)[10]) {
       : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]));
 }
 
-// ---------------------------------------------------------------------------------
-// pair_base = exclusive scan of pair_count (N elements), three small launches.
-__global__ __launch_bounds__(256) void k_scan_reduce(KP P, KB B) {
-  __shared__ int s[256];
-  const int tid = threadIdx.x;
-  const int base = blockIdx.x * kScanBlock + tid * 8;
-  int sum = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) sum += (base + i < P.N) ? P.pair_count[base + i] : 0;
-  s[tid] = sum;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (tid < off) s[tid] += s[tid + off];
-    __syncthreads();
-  }
-  if (tid == 0) B.block_sums[blockIdx.x] = s[0];
-}
-
-__global__ __launch_bounds__(1024) void k_scan_sums(KB B, int nblk) {
-  __shared__ int s[1024];
-  const int tid = threadIdx.x;
-  int carry = 0;
-  for (int base = 0; base < nblk; base += 1024) {
-    const int i = base + tid;
-    const int v = (i < nblk) ? B.block_sums[i] : 0;
-    s[tid] = v;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-      const int t = (tid >= off) ? s[tid - off] : 0;
-      __syncthreads();
-      s[tid] += t;
-      __syncthreads();
-    }
-    if (i < nblk) B.block_sums[i] = carry + s[tid] - v;
-    carry += s[1023];
-    __syncthreads();
-  }
-  if (tid == 0) B.block_sums[nblk] = carry;
-}
-
-__global__ __launch_bounds__(256) void k_scan_write(KP P, KB B) {
-  __shared__ int s[256];
-  const int tid = threadIdx.x;
-  const int base = blockIdx.x * kScanBlock + tid * 8;
-  int v[8], sum = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) { v[i] = (base + i < P.N) ? P.pair_count[base + i] : 0; sum += v[i]; }
-  s[tid] = sum;
-  __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {
-    const int t = (tid >= off) ? s[tid - off] : 0;
-    __syncthreads();
-    s[tid] += t;
-    __syncthreads();
-  }
-  int run = B.block_sums[blockIdx.x] + s[tid] - sum;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    if (base + i < P.N) B.pair_base[base + i] = run;
-    run += v[i];
-  }
-  if (base <= P.N - 1 && P.N - 1 < base + 8) B.pair_base[P.N] = run;
+// Slot of a Gaussian's first pair: pairs of one Gaussian are contiguous and Gaussians are
+// laid out in index order, so the gather pass streams.  The offsets come out of the forward
+// binning (block-local scan + scan of the block totals), no scan is launched here.
+__device__ __forceinline__ int pair_slot_base(const KP& P, int idx) {
+  return P.block_prefix[idx / P.counters[2]] + P.pair_off[idx];
 }
 
 // ---------------------------------------------------------------------------------
@@ -235,7 +178,7 @@ __global__ __launch_bounds__(64) void k_blend_bwd(KP P, KB B) {
     if (jj < nb) {
       const int k = start + base + jj;
       const unsigned int id = (unsigned int)P.keys[k];
-      slot[h] = B.pair_base[id] + (int)P.payload[k];
+      slot[h] = pair_slot_base(P, (int)id) + (int)P.payload[k];
       const float4* src = reinterpret_cast<const float4*>(P.rec + id);
       qa[h] = src[0]; qb[h] = src[1];
       const float4 q2 = src[2];
@@ -521,7 +464,7 @@ __global__ __launch_bounds__(kPreBlock) void k_preprocess_bwd(KP P, KB B) {
     const float p[3] = {P.means[3 * idx], P.means[3 * idx + 1], P.means[3 * idx + 2]};
     if (radius > 0) {
       float a[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      const int s0 = B.pair_base[idx], s1 = B.pair_base[idx + 1];
+      const int s0 = pair_slot_base(P, idx), s1 = s0 + P.pair_count[idx];
       for (int s = s0; s < s1; s++) {
         const float4* src = B.pair_grad + (size_t)s * 3;
         const float4 x = src[0], y = src[1], z = src[2];
@@ -609,10 +552,6 @@ __global__ __launch_bounds__(384) void k_tau_reduce(KB B, int nblk) {
 
 // ---------------------------------------------------------------------------------
 int launch_backward(const KP& P, const KB& B, hipStream_t st) {
-  const int nscan = (P.N + kScanBlock - 1) / kScanBlock;
-  launch("scan_reduce", k_scan_reduce, dim3(nscan), dim3(256), st, P, B);
-  launch("scan_sums", k_scan_sums, dim3(1), dim3(1024), st, B, nscan);
-  launch("scan_write", k_scan_write, dim3(nscan), dim3(256), st, P, B);
   if (B.sketch_mode != 0) {
     const size_t HW = (size_t)P.W * P.H;
     const size_t nacc = (size_t)B.stack_dim * B.sketch_dim * 6;

@@ -66,6 +66,9 @@ int fill_kp(const mgs_forward_args& a, bool need_bins, bool need_outputs, KP& P)
   char* g = (char*)a.geom;
   P.rec = (SplatRec*)(g + L.rec);
   P.pair_count = (int*)(g + L.pair_count);
+  P.pair_off = (int*)(g + L.pair_off);
+  P.block_prefix = (int*)(g + L.block_prefix);
+  P.scan_tmp = (int*)(g + L.scan_tmp);
   P.tile_count = (int*)(g + L.tile_count);
   P.tile_offset = (int*)(g + L.tile_offset);
   P.tile_cursor = (int*)(g + L.tile_cursor);
@@ -147,8 +150,6 @@ int32_t mgs_raster_backward(const mgs_backward_args* args, void* stream) {
   B.grad_color = args->grad_color; B.grad_depth = args->grad_depth;
   char* w = (char*)args->bwd;
   B.pair_grad = (float4*)(w + L.pair_grad);
-  B.pair_base = (int*)(w + L.pair_base);
-  B.block_sums = (int*)(w + L.block_sums);
   B.tau_partial = (float*)(w + L.tau_partial);
   B.g_means3D = args->grad_means3D; B.g_means2D = args->grad_means2D;
   B.g_colors = args->grad_colors; B.g_opac = args->grad_opacities;

@@ -90,9 +90,13 @@ __device__ __forceinline__ void bin_one_pair(const KP& P, int* s_tile, int emit,
 
 __global__ __launch_bounds__(kBinThreads) void k_bin_lds(KP P, int emit, int per_block) {
   extern __shared__ int s_tile[];
+  __shared__ int s_wave[kBinThreads / 64];
+  int carry = 0;
   const int tid = threadIdx.x, lane = tid & 63;
   int* row = P.bin_table + (size_t)blockIdx.x * P.T;
   for (int t = tid; t < P.T; t += kBinThreads) s_tile[t] = emit ? (P.tile_offset[t] + row[t]) : 0;
+  if (emit)   // the blend pass accumulates n_touched; every (re)run of stage 2 starts from zero
+    for (int i = blockIdx.x * kBinThreads + tid; i < P.N; i += gridDim.x * kBinThreads) P.n_touched[i] = 0;
   __syncthreads();
   const int g0 = blockIdx.x * per_block, g1 = min(P.N, g0 + per_block);
   for (int ibase = g0; ibase < g1; ibase += kBinThreads) {
@@ -153,11 +157,38 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_lds(KP P, int emit, int per
       }
       if (lane == src) cnt = total;
     }
-    if (!emit && idx < g1) P.pair_count[idx] = cnt;
+    if (!emit) {
+      // block-local exclusive scan of cnt -> slot offset of this Gaussian inside the block
+      int incl = cnt;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+      }
+      __syncthreads();
+      if (lane == 63) s_wave[tid >> 6] = incl;
+      __syncthreads();
+      int before = 0, total = 0;
+#pragma unroll
+      for (int w = 0; w < kBinThreads / 64; w++) {
+        const int x = s_wave[w];
+        if (w < (tid >> 6)) before += x;
+        total += x;
+      }
+      if (idx < g1) {
+        P.pair_count[idx] = cnt;
+        P.pair_off[idx] = carry + before + incl - cnt;
+      }
+      carry += total;
+    }
   }
   if (!emit) {
     __syncthreads();
     for (int t = tid; t < P.T; t += kBinThreads) row[t] = s_tile[t];
+    if (tid == 0) {
+      P.scan_tmp[blockIdx.x] = carry;          // block total, scanned by k_tile_scan
+      if (blockIdx.x == 0) P.counters[2] = per_block;
+    }
   }
 }
 
@@ -233,11 +264,91 @@ __global__ __launch_bounds__(256) void k_bin(KP P, int emit) {
 }
 
 // ---------------------------------------------------------------------------------
+// Fallback path only (more tiles than fit the LDS table): pair_off = exclusive scan of
+// pair_count over all N Gaussians, three small launches.
+__global__ __launch_bounds__(256) void k_scan_reduce(KP P) {
+  __shared__ int s[256];
+  const int tid = threadIdx.x;
+  const int base = blockIdx.x * kScanBlock + tid * 8;
+  int sum = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) sum += (base + i < P.N) ? P.pair_count[base + i] : 0;
+  s[tid] = sum;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) s[tid] += s[tid + off];
+    __syncthreads();
+  }
+  if (tid == 0) P.scan_tmp[blockIdx.x] = s[0];
+}
+
+__global__ __launch_bounds__(1024) void k_scan_sums(KP P, int nblk) {
+  __shared__ int s[1024];
+  const int tid = threadIdx.x;
+  int carry = 0;
+  for (int base = 0; base < nblk; base += 1024) {
+    const int i = base + tid;
+    const int v = (i < nblk) ? P.scan_tmp[i] : 0;
+    s[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const int t = (tid >= off) ? s[tid - off] : 0;
+      __syncthreads();
+      s[tid] += t;
+      __syncthreads();
+    }
+    if (i < nblk) P.scan_tmp[i] = carry + s[tid] - v;
+    carry += s[1023];
+    __syncthreads();
+  }
+  if (tid == 0) P.scan_tmp[nblk] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_scan_write(KP P) {
+  __shared__ int s[256];
+  const int tid = threadIdx.x;
+  const int base = blockIdx.x * kScanBlock + tid * 8;
+  int v[8], sum = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { v[i] = (base + i < P.N) ? P.pair_count[base + i] : 0; sum += v[i]; }
+  s[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const int t = (tid >= off) ? s[tid - off] : 0;
+    __syncthreads();
+    s[tid] += t;
+    __syncthreads();
+  }
+  int run = P.scan_tmp[blockIdx.x] + s[tid] - sum;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    if (base + i < P.N) P.pair_off[base + i] = run;
+    run += v[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // Exclusive scans of the T tile counts (-> tile_offset, D) and of the per-tile segment
 // counts ceil(n_t / kSeg) (-> seg_offset) by one 1024-thread workgroup.
-__global__ __launch_bounds__(1024) void k_tile_scan(KP P) {
+__global__ __launch_bounds__(1024) void k_tile_scan(KP P, int nbin) {
   __shared__ int s_sum[1024], s_seg[1024];
   const int tid = threadIdx.x;
+  if (nbin > 0) {   // exclusive scan of the binning blocks' pair totals (nbin <= 1024)
+    const int v = tid < nbin ? P.scan_tmp[tid] : 0;
+    s_sum[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const int t = (tid >= off) ? s_sum[tid - off] : 0;
+      __syncthreads();
+      s_sum[tid] += t;
+      __syncthreads();
+    }
+    if (tid < nbin) P.block_prefix[tid] = s_sum[tid] - v;
+    __syncthreads();
+  } else if (tid == 0) {   // fallback path: pair_off already holds the global scan
+    P.block_prefix[0] = 0;
+    P.counters[2] = 0x7fffffff;
+  }
   const int per = (P.T + 1023) / 1024;
   const int lo = tid * per, hi = min(lo + per, P.T);
   int local = 0, lseg = 0;
@@ -520,22 +631,28 @@ int launch_forward_project(const KP& P, hipStream_t st) {
     const int nblk = bin_blocks(P.N), per = (P.N + nblk - 1) / nblk;
     launch_smem("bin_count", k_bin_lds, dim3(nblk), dim3(kBinThreads), sizeof(int) * (size_t)P.T, st, P, 0, per);
     launch("bin_colsum", k_bin_colsum, dim3((P.T + 63) / 64), dim3(64 * kColGroups), st, P, nblk);
+    launch("tile_scan", k_tile_scan, dim3(1), dim3(1024), st, P, nblk);
   } else {
     launch("bin_count", k_bin, dim3((P.N + 255) / 256), dim3(256), st, P, 0);
+    const int nscan = (P.N + kScanBlock - 1) / kScanBlock;
+    launch("scan_reduce", k_scan_reduce, dim3(nscan), dim3(256), st, P);
+    launch("scan_sums", k_scan_sums, dim3(1), dim3(1024), st, P, nscan);
+    launch("scan_write", k_scan_write, dim3(nscan), dim3(256), st, P);
+    launch("tile_scan", k_tile_scan, dim3(1), dim3(1024), st, P, 0);
   }
-  launch("tile_scan", k_tile_scan, dim3(1), dim3(1024), st, P);
   return check_launch();
 }
 
 int launch_forward_blend(const KP& P, hipStream_t st) {
   // cursors restart at 0 on every call so a retry with a larger capacity is valid
-  if (hipMemsetAsync(P.tile_cursor, 0, sizeof(int) * (size_t)P.T, st) != hipSuccess ||
-      hipMemsetAsync(P.n_touched, 0, sizeof(int) * (size_t)P.N, st) != hipSuccess)
-    return MGS_ERR_LAUNCH;
+  // (n_touched is zeroed by the emit pass of the LDS path)
   if (P.T <= kBinMaxTilesLds) {
     const int nblk = bin_blocks(P.N), per = (P.N + nblk - 1) / nblk;
     launch_smem("bin_emit", k_bin_lds, dim3(nblk), dim3(kBinThreads), sizeof(int) * (size_t)P.T, st, P, 1, per);
   } else {
+    if (hipMemsetAsync(P.tile_cursor, 0, sizeof(int) * (size_t)P.T, st) != hipSuccess ||
+        hipMemsetAsync(P.n_touched, 0, sizeof(int) * (size_t)P.N, st) != hipSuccess)
+      return MGS_ERR_LAUNCH;
     launch("bin_emit", k_bin, dim3((P.N + 255) / 256), dim3(256), st, P, 1);
   }
   launch("tile_sort", k_tile_sort<1024, 0>, dim3(P.T), dim3(256), st, P);

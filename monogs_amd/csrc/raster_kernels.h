@@ -19,6 +19,9 @@ struct KP {
   // geom workspace
   SplatRec* rec;
   int* pair_count;
+  int* pair_off;           // N: slot offset of the Gaussian's first pair inside its binning block
+  int* block_prefix;       // kBinBlocks+1: exclusive scan of the blocks' pair totals
+  int* scan_tmp;           // scratch of the fallback N-scan
   int* tile_count;
   int* tile_offset;
   int* tile_cursor;
@@ -42,8 +45,6 @@ struct KP {
 struct KB {   // backward extras
   const float *grad_color, *grad_depth;
   float4* pair_grad;       // cap x 3 float4
-  int* pair_base;          // N+1
-  int* block_sums;         // scan scratch
   float* tau_partial;      // nblocks x 6
   float *g_means3D, *g_means2D, *g_colors, *g_opac, *g_scales, *g_rots, *g_cov, *g_tau;
   int sketch_mode, sketch_dim, stack_dim;
@@ -57,10 +58,10 @@ constexpr uint64_t kAlign = 256;
 inline uint64_t align_up(uint64_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
 
 struct Layout {
-  uint64_t rec, pair_count, tile_count, tile_offset, tile_cursor, bin_table, final_T, final_C,
+  uint64_t rec, pair_count, pair_off, block_prefix, scan_tmp, tile_count, tile_offset, tile_cursor, bin_table, final_T, final_C,
       n_contrib, seg_offset, counters, geom_bytes;
   uint64_t keys, payload, seg_tile, ckpt, max_segs, bins_bytes;
-  uint64_t pair_grad, pair_base, block_sums, tau_partial, bwd_bytes;
+  uint64_t pair_grad, tau_partial, bwd_bytes;
   uint64_t pix_jac, splat_jac, sketch_bytes;
 };
 
@@ -80,6 +81,12 @@ inline Layout make_layout(const mgs_raster_shape& s) {
   uint64_t o = 0;
   L.rec = o; o = align_up(o + N * sizeof(SplatRec));
   L.pair_count = o; o = align_up(o + N * 4);
+  L.pair_off = o; o = align_up(o + N * 4);
+  L.block_prefix = o; o = align_up(o + (uint64_t)(kBinBlocks + 1) * 4);
+  {
+    const uint64_t nscan = (N + kScanBlock - 1) / kScanBlock + 1;
+    L.scan_tmp = o; o = align_up(o + (nscan > (uint64_t)kBinBlocks + 1 ? nscan : (uint64_t)kBinBlocks + 1) * 4);
+  }
   L.tile_count = o; o = align_up(o + T * 4);
   L.tile_offset = o; o = align_up(o + (T + 1) * 4);
   L.tile_cursor = o; o = align_up(o + T * 4);
@@ -99,9 +106,6 @@ inline Layout make_layout(const mgs_raster_shape& s) {
   L.bins_bytes = o;
   o = 0;
   L.pair_grad = o; o = align_up(o + cap * 48);
-  L.pair_base = o; o = align_up(o + (N + 1) * 4);
-  const uint64_t nscan = (N + kScanBlock - 1) / kScanBlock;
-  L.block_sums = o; o = align_up(o + (nscan + 1) * 4);
   const uint64_t npre = (N + kPreBlock - 1) / kPreBlock;
   L.tau_partial = o; o = align_up(o + npre * 6 * 4);
   L.bwd_bytes = o;

@@ -61,6 +61,36 @@ def _round_cap(n: int) -> int:
     return max(1024, (int(n * 1.25) + 1023) // 1024 * 1024)
 
 
+_sizes_cache: dict = {}
+
+
+def _sizes(shape: "_cabi.RasterShape"):
+    """mgs_raster_workspace_query, memoised (pure function of the integer shape)."""
+    key = (shape.num_gaussians, shape.width, shape.height, shape.sh_coeffs, shape.pair_capacity)
+    sz = _sizes_cache.get(key)
+    if sz is None:
+        if len(_sizes_cache) > 256:
+            _sizes_cache.clear()
+        sz = _sizes_cache[key] = _cabi.workspace_sizes(shape)
+    return sz
+
+
+_host_slots: dict = {}
+
+
+def _host_counter(dev_index):
+    """Round-robin pinned int32 slots + events for the asynchronous read of the pair count
+    (allocating pinned memory or an event per call costs more than the kernels it guards)."""
+    ring = _host_slots.get(dev_index)
+    if ring is None:
+        ring = _host_slots[dev_index] = {
+            "buf": torch.empty(8, dtype=torch.int32, pin_memory=True),
+            "ev": [torch.cuda.Event() for _ in range(8)], "i": 0}
+    i = ring["i"]
+    ring["i"] = (i + 1) % 8
+    return ring["buf"][i:i + 1], ring["ev"][i]
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
@@ -92,7 +122,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         hint = _capacity_hint.get(dev.index)
         shape = _cabi.RasterShape(N, W, H, int(st.sh_degree), K, int(hint or 0),
                                   float(st.tanfovx), float(st.tanfovy), float(st.scale_modifier))
-        sizes = _cabi.workspace_sizes(shape)
+        sizes = _sizes(shape)
         geom = torch.empty(int(sizes.geom_bytes), dtype=torch.uint8, device=dev)
         color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
         depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
@@ -115,15 +145,14 @@ class _RasterizeGaussians(torch.autograd.Function):
         _cabi.check(lib.mgs_raster_forward_project(C.byref(a), stream), "mgs_raster_forward_project")
         off = int(sizes.off_counters)
         counter = geom[off:off + 4].view(torch.int32)
-        host_cnt = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        host_cnt, ev = _host_counter(dev.index)
         host_cnt.copy_(counter, non_blocking=True)
-        ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
 
         def run_blend(cap):
             shape.pair_capacity = cap
             a.shape = shape
-            sz = _cabi.workspace_sizes(shape)
+            sz = _sizes(shape)
             bins_ = torch.empty(int(sz.bins_bytes), dtype=torch.uint8, device=dev)
             a.bins = _ptr(bins_)
             _cabi.check(lib.mgs_raster_forward_blend(C.byref(a), stream), "mgs_raster_forward_blend")
@@ -164,7 +193,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         N, W, H, deg, K, cap = ctx.shape_tuple
         shape = _cabi.RasterShape(N, W, H, deg, K, cap, float(st.tanfovx), float(st.tanfovy),
                                   float(st.scale_modifier))
-        sizes = _cabi.workspace_sizes(shape)
+        sizes = _sizes(shape)
         bwd_ws = torch.empty(int(sizes.bwd_bytes), dtype=torch.uint8, device=dev)
         g_means3D = torch.empty(N, 3, dtype=torch.float32, device=dev)
         g_means2D = torch.empty(N, 3, dtype=torch.float32, device=dev)
