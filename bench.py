@@ -125,6 +125,7 @@ def main():
         entry.build()
     from monogs_amd import _cabi, rasterizer as R, synthetic as S
     from monogs_amd.parallel import FlatGradBucket, view_pose
+    from monogs_amd.tracking_fused import l1_image_depth_loss
 
     N, W, H = args.gaussians, args.width, args.height
     sc = S.make_scene(N, W, H, seed=0)
@@ -152,7 +153,8 @@ def main():
         img, radii, dep, opa, nt = ras(means3D=params[0], means2D=m2d, shs=params[4],
                                        opacities=params[3], scales=params[1],
                                        rotations=params[2], theta=theta, rho=rho)
-        loss = (img - gt_img).abs().mean() + 0.05 * (dep - gt_dep).abs().mean()
+        # L = mean|image - G| + 0.05 mean|depth - Gd|, fused HIP loss kernels
+        loss = l1_image_depth_loss(img, dep, gt_img, gt_dep, 0.05)
         loss.backward()
         if bucket is not None and exchange:
             bucket.all_reduce(m2d.grad, radii)

@@ -174,6 +174,38 @@ typedef struct mgs_pose_adam_args {
 
 int32_t mgs_pose_adam_step(const mgs_pose_adam_args* args, void* stream);
 
+/* Mapping objective (utils/slam_utils.py:224-253):
+ *   loss = w_rgb * mean_{3HW} | m ((|a|+eps) image + b - gt) | + w_depth * mean_{HW} | dm (depth - gt_depth) |
+ * m = mask (float 0/1, or NULL), dm = gt_depth > depth_mask_threshold (threshold < 0: no
+ * mask).  Monocular: w_rgb = 1, w_depth = 0; RGB-D: w_rgb = alpha, w_depth = 1 - alpha.
+ * apply_exposure = 0 is `initialization=True`.  `partial` holds
+ * mgs_tracking_loss_partial_count(num_pixels) floats. */
+typedef struct mgs_mapping_loss_args {
+  const float* image;        /* [3,H,W] */
+  const float* gt;           /* [3,H,W] */
+  const float* mask;         /* [1,H,W] or NULL */
+  const float* depth;        /* [1,H,W] or NULL (w_depth == 0) */
+  const float* gt_depth;     /* [1,H,W] or NULL */
+  const float* exposure_a;   /* [1] (apply_exposure != 0) */
+  const float* exposure_b;   /* [1] */
+  float exposure_eps;
+  float w_rgb, w_depth;
+  float depth_mask_threshold;
+  int32_t apply_exposure;
+  int64_t num_pixels;
+  float* partial;
+  float* loss;               /* [1] out */
+  /* backward only */
+  const float* grad_out;     /* [1] */
+  float* grad_image;         /* [3,H,W] */
+  float* grad_depth;         /* [1,H,W] or NULL */
+  float* grad_a;             /* [1] or NULL */
+  float* grad_b;             /* [1] or NULL */
+} mgs_mapping_loss_args;
+
+int32_t mgs_mapping_loss_forward(const mgs_mapping_loss_args* args, void* stream);
+int32_t mgs_mapping_loss_backward(const mgs_mapping_loss_args* args, void* stream);
+
 /* Sketched Levenberg-Marquardt step (utils/slam_frontend.py:672-697 + TempCamera.step
  * :49-53): solves (SJ^T SJ + lambda I) x = -SJ^T Sf for the 8 unknowns
  * [trans(3), rot(3), exposure_a, exposure_b] (identical to the reference's damped

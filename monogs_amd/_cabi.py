@@ -19,7 +19,8 @@ EXPORTS = (
     "mgs_raster_forward_project", "mgs_raster_forward_blend", "mgs_raster_backward",
     "mgs_knn_scratch_bytes", "mgs_knn_dist2", "mgs_profile_enable", "mgs_profile_read",
     "mgs_pose_adam_step", "mgs_tracking_loss_partial_count", "mgs_tracking_loss_forward",
-    "mgs_tracking_loss_backward", "mgs_lm_solve_step",
+    "mgs_tracking_loss_backward", "mgs_lm_solve_step", "mgs_mapping_loss_forward",
+    "mgs_mapping_loss_backward",
 )
 
 _fp = C.c_void_p  # device pointers travel as plain addresses
@@ -60,6 +61,15 @@ class PoseAdamArgs(C.Structure):
         "grad_a", "grad_b", "exp_avg", "exp_avg_sq", "T", "converged")]
         + [("step", C.c_int32)] + [(n, C.c_float) for n in (
             "lr_rot", "lr_trans", "lr_a", "lr_b", "beta1", "beta2", "eps", "converged_threshold")])
+
+
+class MappingLossArgs(C.Structure):
+    _fields_ = ([(n, _fp) for n in ("image", "gt", "mask", "depth", "gt_depth", "exposure_a", "exposure_b")]
+                + [("exposure_eps", C.c_float), ("w_rgb", C.c_float), ("w_depth", C.c_float),
+                   ("depth_mask_threshold", C.c_float), ("apply_exposure", C.c_int32),
+                   ("num_pixels", C.c_int64)]
+                + [(n, _fp) for n in ("partial", "loss", "grad_out", "grad_image", "grad_depth",
+                                      "grad_a", "grad_b")])
 
 
 class LMStepArgs(C.Structure):
@@ -114,6 +124,9 @@ def lib():
                                    C.POINTER(C.c_int32)]
     L.mgs_pose_adam_step.restype = C.c_int32
     L.mgs_pose_adam_step.argtypes = [C.POINTER(PoseAdamArgs), C.c_void_p]
+    for fn in (L.mgs_mapping_loss_forward, L.mgs_mapping_loss_backward):
+        fn.restype = C.c_int32
+        fn.argtypes = [C.POINTER(MappingLossArgs), C.c_void_p]
     L.mgs_lm_solve_step.restype = C.c_int32
     L.mgs_lm_solve_step.argtypes = [C.POINTER(LMStepArgs), C.c_void_p]
     L.mgs_tracking_loss_partial_count.restype = C.c_int32

@@ -256,6 +256,96 @@ __global__ __launch_bounds__(256) void k_lm_solve_step(mgs_lm_step_args A) {
   if (A.exposure_b) A.exposure_b[0] += (float)x[7];
 }
 
+// ---------------------------------------------------------------------------------
+// Mapping objective (utils/slam_utils.py:224-253):
+//   loss = w_rgb * mean_{3HW} | m * ((|a|+eps) img + b - gt) |  +  w_depth * mean_{HW} | dm * (depth - gt_depth) |
+// with m = rgb_pixel_mask_mapping and dm = gt_depth > 0.01 (RGB-D only; w_depth = 0 for
+// monocular).  apply_exposure = 0 reproduces `initialization=True` (image used as is).
+// One streaming pass for the value, one for the gradients.
+__global__ __launch_bounds__(kLossBlock) void k_map_loss_fwd(mgs_mapping_loss_args A) {
+  __shared__ float s_red[kLossBlock / 64];
+  const float gain = A.apply_exposure ? fabsf(A.exposure_a[0]) + A.exposure_eps : 1.f;
+  const float bias = A.apply_exposure ? A.exposure_b[0] : 0.f;
+  const size_t HW = (size_t)A.num_pixels;
+  float sc = 0.f, sd = 0.f;
+  for (size_t p = (size_t)blockIdx.x * kLossBlock + threadIdx.x; p < HW; p += (size_t)gridDim.x * kLossBlock) {
+    const float m = A.mask ? A.mask[p] : 1.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) sc += fabsf(m * (gain * A.image[c * HW + p] + bias - A.gt[c * HW + p]));
+    if (A.w_depth != 0.f) {
+      const float gdp = A.gt_depth[p];
+      const float dm = (A.depth_mask_threshold < 0.f || gdp > A.depth_mask_threshold) ? 1.f : 0.f;
+      sd += fabsf(dm * (A.depth[p] - gdp));
+    }
+  }
+  const float tc = block_sum(sc, s_red);
+  const float td = block_sum(sd, s_red);
+  if (threadIdx.x == 0) { A.partial[blockIdx.x] = tc; A.partial[gridDim.x + blockIdx.x] = td; }
+}
+
+__global__ __launch_bounds__(kLossBlock) void k_map_loss_finish(mgs_mapping_loss_args A, int nblk) {
+  __shared__ float s_red[kLossBlock / 64];
+  float x = 0.f, y = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += kLossBlock) { x += A.partial[i]; y += A.partial[nblk + i]; }
+  const float tc = block_sum(x, s_red);
+  const float td = block_sum(y, s_red);
+  if (threadIdx.x == 0) {
+    const float hw = (float)A.num_pixels;
+    A.loss[0] = A.w_rgb * tc / (3.f * hw) + A.w_depth * td / hw;
+  }
+}
+
+__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+__global__ __launch_bounds__(kLossBlock) void k_map_loss_bwd(mgs_mapping_loss_args A) {
+  __shared__ float s_red[kLossBlock / 64];
+  const float a = A.apply_exposure ? A.exposure_a[0] : 1.f;
+  const float gain = A.apply_exposure ? fabsf(a) + A.exposure_eps : 1.f;
+  const float bias = A.apply_exposure ? A.exposure_b[0] : 0.f;
+  const size_t HW = (size_t)A.num_pixels;
+  const float hw = (float)A.num_pixels;
+  const float kc = A.grad_out[0] * A.w_rgb / (3.f * hw), kd = A.grad_out[0] * A.w_depth / hw;
+  float ga = 0.f, gb = 0.f;
+  for (size_t p = (size_t)blockIdx.x * kLossBlock + threadIdx.x; p < HW; p += (size_t)gridDim.x * kLossBlock) {
+    const float m = A.mask ? A.mask[p] : 1.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float im = A.image[c * HW + p];
+      const float g = kc * m * sgn(m * (gain * im + bias - A.gt[c * HW + p]));
+      A.grad_image[c * HW + p] = g * gain;
+      ga += g * im;
+      gb += g;
+    }
+    if (A.grad_depth) {
+      float g = 0.f;
+      if (A.w_depth != 0.f) {
+        const float gdp = A.gt_depth[p];
+        const float dm = (A.depth_mask_threshold < 0.f || gdp > A.depth_mask_threshold) ? 1.f : 0.f;
+        g = kd * dm * sgn(dm * (A.depth[p] - gdp));
+      }
+      A.grad_depth[p] = g;
+    }
+  }
+  const float ta = block_sum(ga, s_red);
+  const float tb = block_sum(gb, s_red);
+  if (threadIdx.x == 0) {
+    A.partial[blockIdx.x] = ta * sgn(a);
+    A.partial[gridDim.x + blockIdx.x] = tb;
+  }
+}
+
+__global__ __launch_bounds__(kLossBlock) void k_map_loss_bwd_finish(mgs_mapping_loss_args A, int nblk) {
+  __shared__ float s_red[kLossBlock / 64];
+  float x = 0.f, y = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += kLossBlock) { x += A.partial[i]; y += A.partial[nblk + i]; }
+  const float ta = block_sum(x, s_red);
+  const float tb = block_sum(y, s_red);
+  if (threadIdx.x == 0) {
+    if (A.grad_a) A.grad_a[0] = A.apply_exposure ? ta : 0.f;
+    if (A.grad_b) A.grad_b[0] = A.apply_exposure ? tb : 0.f;
+  }
+}
+
 static int loss_blocks(int64_t hw) {
   const int64_t b = (hw + kLossBlock - 1) / kLossBlock;
   return (int)(b < kLossBlocks ? (b < 1 ? 1 : b) : kLossBlocks);
@@ -272,6 +362,29 @@ int32_t mgs_pose_adam_step(const mgs_pose_adam_args* a, void* stream) {
     return MGS_ERR_BAD_ARGUMENT;
   if ((a->grad_a && !a->exposure_a) || (a->grad_b && !a->exposure_b)) return MGS_ERR_BAD_ARGUMENT;
   launch("pose_adam_update", k_pose_adam_update, dim3(1), dim3(64), (hipStream_t)stream, *a);
+  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+}
+
+static bool map_args_ok(const mgs_mapping_loss_args* a) {
+  if (!a || !a->image || !a->gt || !a->partial || !a->loss || a->num_pixels < 1) return false;
+  if (a->apply_exposure && (!a->exposure_a || !a->exposure_b)) return false;
+  if (a->w_depth != 0.f && (!a->depth || !a->gt_depth)) return false;
+  return true;
+}
+
+int32_t mgs_mapping_loss_forward(const mgs_mapping_loss_args* a, void* stream) {
+  if (!map_args_ok(a)) return MGS_ERR_BAD_ARGUMENT;
+  const int nb = loss_blocks(a->num_pixels);
+  launch("map_loss_fwd", k_map_loss_fwd, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a);
+  launch("map_loss_finish", k_map_loss_finish, dim3(1), dim3(kLossBlock), (hipStream_t)stream, *a, nb);
+  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+}
+
+int32_t mgs_mapping_loss_backward(const mgs_mapping_loss_args* a, void* stream) {
+  if (!map_args_ok(a) || !a->grad_out || !a->grad_image) return MGS_ERR_BAD_ARGUMENT;
+  const int nb = loss_blocks(a->num_pixels);
+  launch("map_loss_bwd", k_map_loss_bwd, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a);
+  launch("map_loss_bwd_fin", k_map_loss_bwd_finish, dim3(1), dim3(kLossBlock), (hipStream_t)stream, *a, nb);
   return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
 }
 

@@ -213,7 +213,8 @@ def tracking_step_second_order(viewpoint, gaussians, background, lambda_, repeat
 
 
 def mapping_step(window: List[ViewCamera], gaussians, gaussian_optimizer, keyframe_optimizer,
-                 background, pipe=Pipe, config=DEFAULT_CONFIG, pose_window=3, bucket=None):
+                 background, pipe=Pipe, config=DEFAULT_CONFIG, pose_window=3, bucket=None,
+                 fused_loss=False):
     """One mapping iteration over the keyframe window (slam_backend.py:171-332): render
     every view, sum the mapping losses (+ isotropic-scale regulariser), ONE backward, the
     densification statistics, optimiser steps and update_pose of the first pose_window
@@ -223,7 +224,11 @@ def mapping_step(window: List[ViewCamera], gaussians, gaussian_optimizer, keyfra
     pkgs = []
     for vp in window:
         pkg = render(vp, gaussians, pipe, background)
-        loss = loss + get_loss_mapping(config, pkg["render"], pkg["depth"], vp, pkg["opacity"])
+        if fused_loss:
+            from .tracking_fused import mapping_loss
+            loss = loss + mapping_loss(config, pkg["render"], pkg["depth"], vp)
+        else:
+            loss = loss + get_loss_mapping(config, pkg["render"], pkg["depth"], vp, pkg["opacity"])
         pkgs.append(pkg)
     scaling = gaussians.get_scaling
     loss = loss + 10 * torch.abs(scaling - scaling.mean(dim=1, keepdim=True)).mean()

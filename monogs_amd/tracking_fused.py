@@ -131,3 +131,72 @@ def lm_solve_step(SJ: torch.Tensor, Sf: torch.Tensor, lambda_: float, viewpoint=
     a.x_out = x.data_ptr()
     _cabi.check(_cabi.lib().mgs_lm_solve_step(C.byref(a), _stream(dev)), "mgs_lm_solve_step")
     return x
+
+
+class _MappingLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, depth, gt, gt_depth, mask, exposure_a, exposure_b, exposure_eps, w_rgb,
+                w_depth, depth_mask_threshold, apply_exposure):
+        dev = image.device
+        if dev.type != "cuda":
+            raise RuntimeError("fused mapping loss runs on the GPU only; use monogs_amd.losses on CPU")
+        lib = _cabi.lib()
+        f = lambda t: None if t is None else t.detach().float().contiguous()
+        image_c, depth_c, gt_c, gtd_c, mask_c = f(image), f(depth), f(gt), f(gt_depth), f(mask)
+        HW = int(image_c.shape[-1] * image_c.shape[-2])
+        partial = torch.empty(int(lib.mgs_tracking_loss_partial_count(HW)), dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        a = _cabi.MappingLossArgs()
+        ptr = lambda t: None if t is None else t.data_ptr()
+        a.image, a.gt, a.mask, a.depth, a.gt_depth = ptr(image_c), ptr(gt_c), ptr(mask_c), ptr(depth_c), ptr(gtd_c)
+        a.exposure_a, a.exposure_b = ptr(exposure_a), ptr(exposure_b)
+        a.exposure_eps, a.w_rgb, a.w_depth = float(exposure_eps), float(w_rgb), float(w_depth)
+        a.depth_mask_threshold, a.apply_exposure, a.num_pixels = float(depth_mask_threshold), int(apply_exposure), HW
+        a.partial, a.loss = partial.data_ptr(), loss.data_ptr()
+        _cabi.check(lib.mgs_mapping_loss_forward(C.byref(a), _stream(dev)), "mgs_mapping_loss_forward")
+        ctx.save_for_backward(image_c, depth_c, gt_c, gtd_c, mask_c, exposure_a, exposure_b, partial)
+        ctx.consts = (float(exposure_eps), float(w_rgb), float(w_depth), float(depth_mask_threshold),
+                      int(apply_exposure), HW, depth is not None)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        image_c, depth_c, gt_c, gtd_c, mask_c, exposure_a, exposure_b, partial = ctx.saved_tensors
+        eps, w_rgb, w_depth, thr, apply_exposure, HW, has_depth = ctx.consts
+        dev = image_c.device
+        lib = _cabi.lib()
+        go = grad_out.detach().float().reshape(1).contiguous()
+        g_img = torch.empty_like(image_c)
+        g_dep = torch.empty_like(depth_c) if has_depth else None
+        g_a = torch.empty(1, dtype=torch.float32, device=dev) if apply_exposure else None
+        g_b = torch.empty(1, dtype=torch.float32, device=dev) if apply_exposure else None
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        a = _cabi.MappingLossArgs()
+        ptr = lambda t: None if t is None else t.data_ptr()
+        a.image, a.gt, a.mask, a.depth, a.gt_depth = ptr(image_c), ptr(gt_c), ptr(mask_c), ptr(depth_c), ptr(gtd_c)
+        a.exposure_a, a.exposure_b = ptr(exposure_a), ptr(exposure_b)
+        a.exposure_eps, a.w_rgb, a.w_depth = eps, w_rgb, w_depth
+        a.depth_mask_threshold, a.apply_exposure, a.num_pixels = thr, apply_exposure, HW
+        a.partial, a.loss, a.grad_out = partial.data_ptr(), loss.data_ptr(), go.data_ptr()
+        a.grad_image, a.grad_depth, a.grad_a, a.grad_b = ptr(g_img), ptr(g_dep), ptr(g_a), ptr(g_b)
+        _cabi.check(lib.mgs_mapping_loss_backward(C.byref(a), _stream(dev)), "mgs_mapping_loss_backward")
+        ga = None if g_a is None else g_a.reshape(exposure_a.shape)
+        gb = None if g_b is None else g_b.reshape(exposure_b.shape)
+        return g_img, g_dep, None, None, None, ga, gb, None, None, None, None, None
+
+
+def mapping_loss(config, image, depth, viewpoint, initialization=False):
+    """Fused get_loss_mapping (utils/slam_utils.py:224-253) for `viewpoint`."""
+    mono = config["Training"]["monocular"]
+    alpha = 1.0 if mono else config["Training"].get("alpha", 0.95)
+    return _MappingLoss.apply(image, None if mono else depth, viewpoint.original_image,
+                              None if mono else viewpoint.gt_depth, viewpoint.rgb_pixel_mask_mapping,
+                              viewpoint.exposure_a, viewpoint.exposure_b, viewpoint.exposure_eps,
+                              alpha, 0.0 if mono else 1.0 - alpha, 0.01, 0 if initialization else 1)
+
+
+def l1_image_depth_loss(image, depth, gt_image, gt_depth, w_depth=0.05):
+    """mean|image - gt| + w_depth * mean|depth - gt_depth| (the synthetic benchmark loss of
+    BASELINE.md §4) through the same fused kernels."""
+    return _MappingLoss.apply(image, depth, gt_image, gt_depth, None, None, None, 0.0, 1.0, w_depth,
+                              -1.0, 0)

@@ -713,3 +713,53 @@ def test_wave_reduce_scatter_unit(built, tmp_path):
                            os.path.join(root, "tests", "hip", "test_wave_reduce.hip"), "-o", exe])
     out = subprocess.run([exe], stdout=subprocess.PIPE, text=True, timeout=60)
     assert out.returncode == 0 and "PASS" in out.stdout, out.stdout
+
+
+def test_fused_mapping_loss_matches_torch_reference(built):
+    from monogs_amd import losses as Ls
+    from monogs_amd.tracking_fused import l1_image_depth_loss, mapping_loss
+    dev = _dev()
+    g = torch.Generator().manual_seed(2)
+    H, W = 90, 130
+
+    class VP:
+        pass
+
+    for mono, init in ((True, False), (False, False), (True, True)):
+        vp = VP()
+        vp.original_image = torch.rand(3, H, W, generator=g).to(dev)
+        vp.rgb_pixel_mask_mapping = (torch.rand(1, H, W, generator=g) > 0.2).to(dev)
+        vp.gt_depth = (torch.rand(1, H, W, generator=g) * 4).to(dev)
+        vp.gt_depth[vp.gt_depth < 0.5] = 0.0
+        vp.exposure_a = torch.tensor([-0.8], device=dev, requires_grad=True)
+        vp.exposure_b = torch.tensor([0.07], device=dev, requires_grad=True)
+        vp.exposure_eps = 1e-8
+        cfg = {"Training": {"monocular": mono, "alpha": 0.9}}
+        img = torch.rand(3, H, W, generator=g).to(dev).requires_grad_()
+        dep = (torch.rand(1, H, W, generator=g) * 4).to(dev).requires_grad_()
+        ref = Ls.get_loss_mapping(cfg, img, dep, vp, None, initialization=init)
+        (3.0 * ref).backward()
+        want = [ref.item(), img.grad.clone(), None if dep.grad is None else dep.grad.clone(),
+                None if vp.exposure_a.grad is None else vp.exposure_a.grad.clone(),
+                None if vp.exposure_b.grad is None else vp.exposure_b.grad.clone()]
+        for t in (img, dep, vp.exposure_a, vp.exposure_b):
+            t.grad = None
+        got = mapping_loss(cfg, img, dep, vp, initialization=init)
+        (3.0 * got).backward()
+        assert abs(got.item() - want[0]) <= 1e-5 * abs(want[0])
+        assert rel_err(img.grad, want[1]) < 1e-5
+        if not mono:
+            assert rel_err(dep.grad, want[2]) < 1e-5
+        if not init:
+            assert rel_err(vp.exposure_a.grad, want[3]) < 1e-4 and rel_err(vp.exposure_b.grad, want[4]) < 1e-4
+    img = torch.rand(3, H, W, generator=g).to(dev).requires_grad_()
+    dep = torch.rand(1, H, W, generator=g).to(dev).requires_grad_()
+    gi, gd = torch.rand(3, H, W, generator=g).to(dev), torch.rand(1, H, W, generator=g).to(dev)
+    ref = (img - gi).abs().mean() + 0.05 * (dep - gd).abs().mean()
+    ref.backward()
+    w = (ref.item(), img.grad.clone(), dep.grad.clone())
+    img.grad = None
+    dep.grad = None
+    got = l1_image_depth_loss(img, dep, gi, gd, 0.05)
+    got.backward()
+    assert abs(got.item() - w[0]) < 1e-5 * w[0] and rel_err(img.grad, w[1]) < 1e-5 and rel_err(dep.grad, w[2]) < 1e-5
