@@ -196,14 +196,15 @@ __global__ __launch_bounds__(64) void k_blend_bwd(KP P, KB B) {
   }
 
   // ---- per-pixel data: pixel q of this lane is tile pixel lane + 64 q --------------------
-  // State per pixel: T (transmittance in front of the next splat) and S = colour/depth still
-  // to come BEHIND the splats visited so far, background included:
-  //   S = (C_final + T_final * bg) - F,  F = prefix colour from the checkpoint.
-  // Keeping S instead of (C_final, F) saves 16 VGPRs and folds the background term of
-  // dL/dalpha into the same expression.
+  // State per pixel: T (transmittance in front of the next splat) and the scalar
+  //   gS = sum_ch dL/dC_ch * S_ch,   S = (C_final + T_final * bg) - F
+  // (S = colour/depth still to come BEHIND the splats visited so far, background included,
+  // F = prefix colour from the checkpoint).  dL/dalpha only ever needs S through g.S, and
+  // g.S updates with one FMA per splat (gS -= w * g.c), so the four S channels never live
+  // in registers.
   int last[4];
   v2f gA0, gA1, gA2, gAd, gB0, gB1, gB2, gBd;        // dL/dC, dL/dD   (A: q=0,1  B: q=2,3)
-  v2f sA0, sA1, sA2, sAd, sB0, sB1, sB2, sBd;        // S
+  v2f gSA, gSB;                                       // g . S
   v2f TA = {1.f, 1.f}, TB = {1.f, 1.f};
   const float bg0 = P.bg[0], bg1 = P.bg[1], bg2 = P.bg[2];
   const float* ck = (seg > 0) ? P.ckpt + (size_t)item * (5 * 256) : nullptr;
@@ -230,11 +231,11 @@ __global__ __launch_bounds__(64) void k_blend_bwd(KP P, KB B) {
     }
     const int e = q & 1;
     if (q < 2) {
-      gA0[e] = g0; gA1[e] = g1; gA2[e] = g2; gAd[e] = gd; sA0[e] = c0; sA1[e] = c1; sA2[e] = c2;
-      sAd[e] = cd; TA[e] = t;
+      gA0[e] = g0; gA1[e] = g1; gA2[e] = g2; gAd[e] = gd;
+      gSA[e] = g0 * c0 + g1 * c1 + g2 * c2 + gd * cd; TA[e] = t;
     } else {
-      gB0[e] = g0; gB1[e] = g1; gB2[e] = g2; gBd[e] = gd; sB0[e] = c0; sB1[e] = c1; sB2[e] = c2;
-      sBd[e] = cd; TB[e] = t;
+      gB0[e] = g0; gB1[e] = g1; gB2[e] = g2; gBd[e] = gd;
+      gSB[e] = g0 * c0 + g1 * c1 + g2 * c2 + gd * cd; TB[e] = t;
     }
   }
   // does any pixel of the tile reach this segment?
@@ -287,15 +288,14 @@ __global__ __launch_bounds__(64) void k_blend_bwd(KP P, KB B) {
       const v2f aeA = v2f{k0 ? alA.x : 0.f, k1 ? alA.y : 0.f};
       const v2f aeB = v2f{k2 ? alB.x : 0.f, k3 ? alB.y : 0.f};
       const v2f wA = aeA * TA, wB = aeB * TB;
-      sA0 -= v.w * wA; sA1 -= cgb.x * wA; sA2 -= cgb.y * wA; sAd -= v.z * wA;
-      sB0 -= v.w * wB; sB1 -= cgb.x * wB; sB2 -= cgb.y * wB; sBd -= v.z * wB;
+      // g . c (c is the splat's colour/depth, uniform over the wave)
+      const v2f gcA = gA0 * v.w + gA1 * cgb.x + gA2 * cgb.y + gAd * v.z;
+      const v2f gcB = gB0 * v.w + gB1 * cgb.x + gB2 * cgb.y + gBd * v.z;
+      gSA -= wA * gcA; gSB -= wB * gcB;
       const v2f omA = 1.f - aeA, omB = 1.f - aeB;
       const v2f roA = v2f{__builtin_amdgcn_rcpf(omA.x), __builtin_amdgcn_rcpf(omA.y)};
       const v2f roB = v2f{__builtin_amdgcn_rcpf(omB.x), __builtin_amdgcn_rcpf(omB.y)};
-      const v2f dA = gA0 * (v.w * TA - sA0 * roA) + gA1 * (cgb.x * TA - sA1 * roA) +
-                     gA2 * (cgb.y * TA - sA2 * roA) + gAd * (v.z * TA - sAd * roA);
-      const v2f dB = gB0 * (v.w * TB - sB0 * roB) + gB1 * (cgb.x * TB - sB1 * roB) +
-                     gB2 * (cgb.y * TB - sB2 * roB) + gBd * (v.z * TB - sBd * roB);
+      const v2f dA = TA * gcA - roA * gSA, dB = TB * gcB - roB * gSB;
       TA *= omA; TB *= omB;
       v2f WA = arA * dA, WB = arB * dB;
       WA = v2f{k0 ? WA.x : 0.f, k1 ? WA.y : 0.f};
