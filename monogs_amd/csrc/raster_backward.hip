@@ -153,7 +153,7 @@ __global__ __launch_bounds__(64) void k_blend_bwd(KP P, KB B) {
   __shared__ float2 s_r2[kSeg];
   __shared__ float4 s_out[kSeg][3];
   __shared__ float4 s_coef[SKETCH ? kSeg : 1][9];   // per splat: 6 tau components x 6 coefficients
-  const int item = blockIdx.x, lane = threadIdx.x;
+  const int item = xcd_remap<kBwdChunk>(blockIdx.x), lane = threadIdx.x;
   if (item >= min(P.seg_offset[P.T], P.max_segs)) return;
   const int tile = P.seg_tile[item];
   const int seg = item - P.seg_offset[tile];
@@ -560,10 +560,10 @@ int launch_backward(const KP& P, const KB& B, hipStream_t st) {
         hipMemsetAsync(B.g_sketch, 0, nacc * sizeof(float), st) != hipSuccess)
       return MGS_ERR_LAUNCH;
     launch("sketch_prep", k_sketch_prep, dim3((P.N + kPreBlock - 1) / kPreBlock), dim3(kPreBlock), st, P, B);
-    launch("blend_bwd_sketch", k_blend_bwd<true>, dim3(P.max_segs), dim3(64), st, P, B);
+    launch("blend_bwd_sketch", k_blend_bwd<true>, dim3(grid_pad(P.max_segs, kBwdChunk)), dim3(64), st, P, B);
     launch_smem("sketch_bucket", k_sketch_bucket, dim3(kBucketBlocks), dim3(256), nacc * sizeof(float), st, P, B);
   } else {
-    launch("blend_bwd", k_blend_bwd<false>, dim3(P.max_segs), dim3(64), st, P, B);
+    launch("blend_bwd", k_blend_bwd<false>, dim3(grid_pad(P.max_segs, kBwdChunk)), dim3(64), st, P, B);
   }
   const int npre = (P.N + kPreBlock - 1) / kPreBlock;
   launch("preprocess_bwd", k_preprocess_bwd, dim3(npre), dim3(kPreBlock), st, P, B);

@@ -515,7 +515,8 @@ __global__ __launch_bounds__(kFwdThreads) void k_blend_fwd(KP P) {
   __shared__ unsigned int s_id[kFwdStage];
   __shared__ unsigned int s_mask[kFwdStage];
   __shared__ int s_cnt[kFwdStage];
-  const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = blockIdx.x;   // (an XCD-chunked order was measured: no gain for the forward)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tx = tile % P.grid_x, ty = tile / P.grid_x;
   const int qx0 = tx * kTile + 8 * (wave & 1), qy0 = ty * kTile + 8 * (wave >> 1);
   const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);

@@ -54,6 +54,22 @@ struct KB {   // backward extras
   float* splat_jac;        // N x 36 per-splat d(xy,conic,depth)/dtau (sketch mode)
 };
 
+// XCD-aware work-item order (cdna_hip_programming.md T1): workgroups are dealt round-robin
+// over the 8 XCDs, so with the identity mapping neighbouring tiles / the segments of one
+// tile - which share splat records, per-pixel gradients and checkpoints - land in 8
+// different L2s.  Here every XCD instead receives CHUNK consecutive logical items at a
+// time, chunks dealt round-robin (a contiguous eighth of the grid per XCD would unbalance
+// the XCDs: work per tile varies smoothly over the image and the padded tail is empty).
+// Bijective on a grid padded to a multiple of 8*CHUNK.  Speed only: results do not depend
+// on placement.
+template <int CHUNK>
+__device__ __forceinline__ int xcd_remap(int bid) {
+  const int xcd = bid & 7, slot = bid >> 3;
+  return ((slot / CHUNK) * 8 + xcd) * CHUNK + (slot % CHUNK);
+}
+inline int grid_pad(int n, int chunk) { const int q = 8 * chunk; return (n + q - 1) / q * q; }
+constexpr int kBwdChunk = 16;
+
 constexpr uint64_t kAlign = 256;
 inline uint64_t align_up(uint64_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
 
