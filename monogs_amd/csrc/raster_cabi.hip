@@ -25,7 +25,8 @@ namespace mgs {
 int launch_forward_project(const KP& P, hipStream_t st);
 int launch_forward_blend(const KP& P, hipStream_t st);
 int launch_backward(const KP& P, const KB& B, hipStream_t st);
-int launch_knn(const float* pts, int n, float* out, hipStream_t st);
+int launch_knn(const float* pts, int n, float* out, void* scratch, hipStream_t st);
+uint64_t knn_scratch_bytes(int n);
 }  // namespace mgs
 
 using namespace mgs;
@@ -198,13 +199,12 @@ int32_t mgs_profile_read(int32_t max_entries, char* names, float* total_ms, int3
   return n;
 }
 
-uint64_t mgs_knn_scratch_bytes(int32_t num_points) { (void)num_points; return 256; }
+uint64_t mgs_knn_scratch_bytes(int32_t num_points) { return num_points < 1 ? 256 : knn_scratch_bytes(num_points); }
 
 int32_t mgs_knn_dist2(const float* points, int32_t num_points, float* out, void* scratch,
                       void* stream) {
-  (void)scratch;
-  if (!points || !out || num_points < 1) return MGS_ERR_BAD_ARGUMENT;
-  return launch_knn(points, num_points, out, (hipStream_t)stream);
+  if (!points || !out || !scratch || num_points < 1) return MGS_ERR_BAD_ARGUMENT;
+  return launch_knn(points, num_points, out, scratch, (hipStream_t)stream);
 }
 
 }  // extern "C"

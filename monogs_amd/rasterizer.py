@@ -167,7 +167,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         if bins is None or D > shape.pair_capacity:
             retried = bins is not None
             bins = run_blend(_round_cap(D))
-        _capacity_hint[dev.index] = max(_round_cap(D), int(shape.pair_capacity))
+        # high-water mark with slow decay, so one unusually heavy view does not pin memory forever
+        _capacity_hint[dev.index] = max(_round_cap(D), int(shape.pair_capacity * 0.97) // 1024 * 1024)
         last_stats.update(pairs=D, capacity=int(shape.pair_capacity), retried=retried, N=N)
 
         ctx.raster_settings = st
@@ -258,6 +259,14 @@ class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings: GaussianRasterizationSettings):
         super().__init__()
         self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        """Frustum test of the extension's `markVisible` (unused by MonoGS): the near-plane
+        test the rasteriser itself applies, p_view.z > 0.2."""
+        with torch.no_grad():
+            V = self.raster_settings.viewmatrix.to(positions.device, torch.float32)
+            z = positions.float() @ V[:3, 2] + V[3, 2]
+            return z > 0.2
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,
                 rotations=None, cov3D_precomp=None, theta=None, rho=None,

@@ -763,3 +763,24 @@ def test_fused_mapping_loss_matches_torch_reference(built):
     got = l1_image_depth_loss(img, dep, gi, gd, 0.05)
     got.backward()
     assert abs(got.item() - w[0]) < 1e-5 * w[0] and rel_err(img.grad, w[1]) < 1e-5 and rel_err(dep.grad, w[2]) < 1e-5
+
+
+def test_inputs_without_grad_mixed_dtypes_and_mark_visible(built):
+    """No input requires grad (eval / GUI rendering, eval_utils.py:138): forward only works,
+    non-contiguous and fp64 inputs are accepted, markVisible agrees with radii > 0 on the
+    near-plane criterion."""
+    from monogs_amd import synthetic as S
+    from monogs_amd.rasterizer import GaussianRasterizer
+    dev = _dev()
+    sc = S.make_scene(700, 96, 64, seed=40)
+    m, s, r, o, sh = [t.to(dev) for t in _inputs(sc)]
+    m[:50, 2] = -1.0
+    ras = GaussianRasterizer(gpu_settings(sc.cam, sc.bg, dev))
+    with torch.no_grad():
+        a = ras(means3D=m, means2D=torch.zeros_like(m), opacities=o, shs=sh, scales=s, rotations=r)
+        m_nc = torch.stack([m, m], 1)[:, 0]                       # non-contiguous view
+        b = ras(means3D=m_nc.double(), means2D=torch.zeros_like(m), opacities=o.double(), shs=sh.double(),
+                scales=s.double(), rotations=r.double())
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    vis = ras.markVisible(m)
+    assert not vis[:50].any() and ((a[1] > 0) <= vis).all()
