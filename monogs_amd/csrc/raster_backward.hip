@@ -384,17 +384,15 @@ __global__ __launch_bounds__(kPreBlock) void k_sketch_prep(KP P, KB B) {
   Camera cam;
   load_camera_b(cam, P);
   const float p[3] = {P.means[3 * idx], P.means[3 * idx + 1], P.means[3 * idx + 2]};
-  float sc[3], q[4], c6[6];
-  const float *psc = nullptr, *pq = nullptr, *pc6 = nullptr;
-  if (P.covp) {
+  float sc[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool has_cov = P.covp != nullptr;
+  if (has_cov) {
 #pragma unroll
     for (int i = 0; i < 6; i++) c6[i] = P.covp[6 * (size_t)idx + i];
-    pc6 = c6;
   } else {
     sc[0] = P.scales[3 * idx]; sc[1] = P.scales[3 * idx + 1]; sc[2] = P.scales[3 * idx + 2];
     const float4 qq = reinterpret_cast<const float4*>(P.rots)[idx];
     q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w;
-    psc = sc; pq = q;
   }
   float M[6][6];   // rows: x, y, A, B, C, depth ; columns: tau
 #pragma unroll
@@ -402,7 +400,8 @@ __global__ __launch_bounds__(kPreBlock) void k_sketch_prep(KP P, KB B) {
     const float g_xy[2] = {row == 0 ? 1.f : 0.f, row == 1 ? 1.f : 0.f};
     const float g_con[3] = {row == 2 ? 1.f : 0.f, row == 3 ? 1.f : 0.f, row == 4 ? 1.f : 0.f};
     GaussGrad gg;
-    project_gaussian_backward(cam, p, psc, pq, pc6, g_xy, g_con, 0.f, row == 5 ? 1.f : 0.f, gg);
+    if (has_cov) project_gaussian_backward(cam, p, nullptr, nullptr, c6, g_xy, g_con, 0.f, row == 5 ? 1.f : 0.f, gg);
+    else project_gaussian_backward(cam, p, sc, q, nullptr, g_xy, g_con, 0.f, row == 5 ? 1.f : 0.f, gg);
 #pragma unroll
     for (int t = 0; t < 6; t++) M[row][t] = gg.dtau[t];
   }
@@ -474,22 +473,20 @@ __global__ __launch_bounds__(kPreBlock) void k_preprocess_bwd(KP P, KB B) {
       }
       Camera cam;
       load_camera_b(cam, P);
-      float sc[3], q[4], c6[6];
-      const float *psc = nullptr, *pq = nullptr, *pc6 = nullptr;
-      if (P.covp) {
-#pragma unroll
-        for (int i = 0; i < 6; i++) c6[i] = P.covp[6 * (size_t)idx + i];
-        pc6 = c6;
-      } else {
-        sc[0] = P.scales[3 * idx]; sc[1] = P.scales[3 * idx + 1]; sc[2] = P.scales[3 * idx + 2];
-        const float4 qq = reinterpret_cast<const float4*>(P.rots)[idx];
-        q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w;
-        psc = sc; pq = q;
-      }
       const float g_xy[2] = {a[0], a[1]};
       const float g_con[3] = {a[2], a[3], a[4]};
       GaussGrad gg;
-      project_gaussian_backward(cam, p, psc, pq, pc6, g_xy, g_con, a[5], a[9], gg);
+      if (P.covp) {
+        float c6[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) c6[i] = P.covp[6 * (size_t)idx + i];
+        project_gaussian_backward(cam, p, nullptr, nullptr, c6, g_xy, g_con, a[5], a[9], gg);
+      } else {
+        const float sc[3] = {P.scales[3 * idx], P.scales[3 * idx + 1], P.scales[3 * idx + 2]};
+        const float4 qq = reinterpret_cast<const float4*>(P.rots)[idx];
+        const float q[4] = {qq.x, qq.y, qq.z, qq.w};
+        project_gaussian_backward(cam, p, sc, q, nullptr, g_xy, g_con, a[5], a[9], gg);
+      }
 #pragma unroll
       for (int i = 0; i < 3; i++) { dmean[i] = gg.dmean[i]; dscale[i] = gg.dscale[i]; grgb[i] = a[6 + i]; }
 #pragma unroll

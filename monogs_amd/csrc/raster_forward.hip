@@ -33,27 +33,22 @@ __global__ __launch_bounds__(kPreBlock) void k_preprocess(KP P) {
   Camera cam;
   load_camera(cam, P);
   const float p[3] = {P.means[3 * idx], P.means[3 * idx + 1], P.means[3 * idx + 2]};
-  float sc[3], q[4], c6[6];
-  const float *psc = nullptr, *pq = nullptr, *pc6 = nullptr;
-  if (P.covp) {
-#pragma unroll
-    for (int i = 0; i < 6; i++) c6[i] = P.covp[6 * (size_t)idx + i];
-    pc6 = c6;
-  } else {
-    sc[0] = P.scales[3 * idx]; sc[1] = P.scales[3 * idx + 1]; sc[2] = P.scales[3 * idx + 2];
-    const float4 qq = reinterpret_cast<const float4*>(P.rots)[idx];
-    q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w;
-    psc = sc; pq = q;
-  }
-  float col[3];
-  const float* pcol = nullptr;
-  if (P.precol) {
-    col[0] = P.precol[3 * idx]; col[1] = P.precol[3 * idx + 1]; col[2] = P.precol[3 * idx + 2];
-    pcol = col;
-  }
+  const float* pcol = P.precol ? P.precol + (size_t)3 * idx : nullptr;   // read in place
   const float* psh = P.shs ? P.shs + (size_t)3 * P.K * idx : nullptr;
   SplatRec rec;
-  project_gaussian(cam, p, psc, pq, pc6, psh, pcol, P.opac[idx], rec);
+  // two call sites instead of selecting between pointers to local arrays: a pointer select
+  // forces the arrays into scratch memory
+  if (P.covp) {
+    float c6[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) c6[i] = P.covp[6 * (size_t)idx + i];
+    project_gaussian(cam, p, nullptr, nullptr, c6, psh, pcol, P.opac[idx], rec);
+  } else {
+    const float sc[3] = {P.scales[3 * idx], P.scales[3 * idx + 1], P.scales[3 * idx + 2]};
+    const float4 qq = reinterpret_cast<const float4*>(P.rots)[idx];
+    const float q[4] = {qq.x, qq.y, qq.z, qq.w};
+    project_gaussian(cam, p, sc, q, nullptr, psh, pcol, P.opac[idx], rec);
+  }
   float4* dst = reinterpret_cast<float4*>(P.rec + idx);
   dst[0] = make_float4(rec.x, rec.y, rec.depth, rec.opacity);
   dst[1] = make_float4(rec.ca, rec.cb, rec.cc, __int_as_float(rec.radius));
