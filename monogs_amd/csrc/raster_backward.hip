@@ -127,8 +127,12 @@ __device__ __forceinline__ int pair_slot_base(const KP& P, int idx) {
 
 // ---------------------------------------------------------------------------------
 // Blend backward, segment-parallel.  One wave per (tile, kSeg-splat segment) work item,
-// FOUR pixels per lane (rows y, y+4, y+8, y+12 of one column: dx is shared, the fp32 work
-// packs into v_pk_*).  The forward checkpointed the per-pixel blend state (T, prefix
+// FOUR pixels per lane, one in each 8x8 quadrant of the tile.  The lane that stages a splat
+// also evaluates the culling bound on the four quadrant boxes; the wave then visits, per
+// splat, only the quadrants that can be reached (wave-uniform branches).  Packed fp32 is
+// deliberately not used: v_pk_fma_f32 occupies the SIMD for twice the cycles of
+// v_fma_f32, so it saves issue slots but no pipe time, whereas per-quadrant skipping
+// removes about half of the arithmetic for splats of a few pixels' extent.  The forward checkpointed the per-pixel blend state (T, prefix
 // colour F) in front of every segment, so items are independent: no serial chain over a
 // tile's whole list, ~D/kSeg equal-sized items instead of T ragged ones.
 //
@@ -149,8 +153,10 @@ constexpr float kLog2eB = 1.4426950408889634f;
 
 template <bool SKETCH>
 __global__ __launch_bounds__(64) void k_blend_bwd(KP P, KB B) {
+  static_assert(kSeg == 64, "one staged record per lane");
   __shared__ float4 s_r0[kSeg], s_r1[kSeg];
   __shared__ float2 s_r2[kSeg];
+  __shared__ unsigned int s_mask[kSeg];
   __shared__ float4 s_out[kSeg][3];
   __shared__ float4 s_coef[SKETCH ? kSeg : 1][9];   // per splat: 6 tau components x 6 coefficients
   const int item = xcd_remap<kBwdChunk>(blockIdx.x), lane = threadIdx.x;
@@ -163,203 +169,176 @@ __global__ __launch_bounds__(64) void k_blend_bwd(KP P, KB B) {
   const int nb = min(kSeg, end - start - base);
   if (nb <= 0) return;
   const int tx = tile % P.grid_x, ty = tile / P.grid_x;
-  const int px = tx * kTile + (lane & 15);
-  const int pyb = ty * kTile + (lane >> 4);
+  // Pixel q of this lane lies in QUADRANT q of the tile: (qx + 8 (q & 1), qy + 8 (q >> 1)).
+  const int qx = tx * kTile + (lane & 7), qy = ty * kTile + (lane >> 3);
   const size_t HW = (size_t)P.W * P.H;
 
-  // ---- stage the segment's records (2 per lane), remember slot + raw conic ---------
-  constexpr int kStage = kSeg / 64;   // records staged per lane
-  int slot[kStage];
-  float4 qa[kStage], qb[kStage];
-#pragma unroll
-  for (int h = 0; h < kStage; h++) {
-    slot[h] = -1;
-    const int jj = lane + 64 * h;
-    if (jj < nb) {
-      const int k = start + base + jj;
+  // ---- stage the segment's records (one per lane): slot, raw conic, quadrant reach mask ---
+  int slot = -1;
+  float4 qa, qb;
+  {
+    unsigned int mask4 = 0;
+    if (lane < nb) {
+      const int k = start + base + lane;
       const unsigned int id = (unsigned int)P.keys[k];
-      slot[h] = pair_slot_base(P, (int)id) + (int)P.payload[k];
+      slot = pair_slot_base(P, (int)id) + (int)P.payload[k];
       const float4* src = reinterpret_cast<const float4*>(P.rec + id);
-      qa[h] = src[0]; qb[h] = src[1];
+      qa = src[0]; qb = src[1];
       const float4 q2 = src[2];
-      s_r0[jj] = make_float4(qa[h].x, qa[h].y, -0.5f * kLog2eB * qb[h].x, -kLog2eB * qb[h].y);
-      s_r1[jj] = make_float4(-0.5f * kLog2eB * qb[h].z, qa[h].w, qa[h].z, q2.x);
-      s_r2[jj] = make_float2(q2.y, q2.z);
+      s_r0[lane] = make_float4(qa.x, qa.y, -0.5f * kLog2eB * qb.x, -kLog2eB * qb.y);
+      s_r1[lane] = make_float4(-0.5f * kLog2eB * qb.z, qa.w, qa.z, q2.x);
+      s_r2[lane] = make_float2(q2.y, q2.z);
       if constexpr (SKETCH) {
         const float4* cj = reinterpret_cast<const float4*>(B.splat_jac + (size_t)id * 36);
 #pragma unroll
-        for (int i = 0; i < 9; i++) s_coef[jj][i] = cj[i];
+        for (int i = 0; i < 9; i++) s_coef[lane][i] = cj[i];
+      }
+      const float qmax = splat_qmax(qa.w);
+      const float Wm = (float)(P.W - 1), Hm = (float)(P.H - 1);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const float x0 = (float)(tx * kTile + 8 * (q & 1)), y0 = (float)(ty * kTile + 8 * (q >> 1));
+        if (x0 <= Wm && y0 <= Hm &&
+            box_reachable(qa.x, qa.y, qb.x, qb.y, qb.z, qmax, x0, y0, fminf(x0 + 7.f, Wm), fminf(y0 + 7.f, Hm)))
+          mask4 |= 1u << q;
       }
     }
+    s_mask[lane] = mask4;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    s_out[jj][0] = z; s_out[jj][1] = z; s_out[jj][2] = z;
+    s_out[lane][0] = z; s_out[lane][1] = z; s_out[lane][2] = z;
   }
 
-  // ---- per-pixel data: pixel q of this lane is tile pixel lane + 64 q --------------------
-  // State per pixel: T (transmittance in front of the next splat) and the scalar
+  // ---- per-pixel state ----------------------------------------------------------------------
+  // T (transmittance in front of the next splat) and the scalar
   //   gS = sum_ch dL/dC_ch * S_ch,   S = (C_final + T_final * bg) - F
   // (S = colour/depth still to come BEHIND the splats visited so far, background included,
   // F = prefix colour from the checkpoint).  dL/dalpha only ever needs S through g.S, and
-  // g.S updates with one FMA per splat (gS -= w * g.c), so the four S channels never live
-  // in registers.
+  // g.S updates with one FMA per splat (gS -= w * g.c).
   int last[4];
-  v2f gA0, gA1, gA2, gAd, gB0, gB1, gB2, gBd;        // dL/dC, dL/dD   (A: q=0,1  B: q=2,3)
-  v2f gSA, gSB;                                       // g . S
-  v2f TA = {1.f, 1.f}, TB = {1.f, 1.f};
+  float g0[4], g1[4], g2[4], gd[4], T[4], gS[4];
   const float bg0 = P.bg[0], bg1 = P.bg[1], bg2 = P.bg[2];
   const float* ck = (seg > 0) ? P.ckpt + (size_t)item * (5 * 256) : nullptr;
 #pragma unroll
   for (int q = 0; q < 4; q++) {
-    const int py = pyb + 4 * q;
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f, gd = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, cd = 0.f;
-    int l = 0;
+    const int px = qx + 8 * (q & 1), py = qy + 8 * (q >> 1);
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, cd = 0.f;
+    g0[q] = g1[q] = g2[q] = gd[q] = 0.f;
+    last[q] = 0;
+    T[q] = 1.f;
     if (px < P.W && py < P.H) {
       const size_t pix = (size_t)py * P.W + px;
-      l = P.n_contrib[pix];
-      g0 = B.grad_color[pix]; g1 = B.grad_color[HW + pix]; g2 = B.grad_color[2 * HW + pix];
-      if (B.grad_depth) gd = B.grad_depth[pix];
+      last[q] = P.n_contrib[pix];
+      g0[q] = B.grad_color[pix]; g1[q] = B.grad_color[HW + pix]; g2[q] = B.grad_color[2 * HW + pix];
+      if (B.grad_depth) gd[q] = B.grad_depth[pix];
       const float tf = P.final_T[pix];
       c0 = P.final_C[pix] + tf * bg0; c1 = P.final_C[HW + pix] + tf * bg1;
       c2 = P.final_C[2 * HW + pix] + tf * bg2;
       cd = P.final_C[3 * HW + pix];
     }
-    last[q] = l;
-    float t = 1.f;
     if (ck) {
-      const int p = lane + 64 * q;
-      t = ck[p]; c0 -= ck[256 + p]; c1 -= ck[512 + p]; c2 -= ck[768 + p]; cd -= ck[1024 + p];
+      const int p = (py - ty * kTile) * kTile + (px - tx * kTile);   // pixel index in the tile
+      T[q] = ck[p]; c0 -= ck[256 + p]; c1 -= ck[512 + p]; c2 -= ck[768 + p]; cd -= ck[1024 + p];
     }
-    const int e = q & 1;
-    if (q < 2) {
-      gA0[e] = g0; gA1[e] = g1; gA2[e] = g2; gAd[e] = gd;
-      gSA[e] = g0 * c0 + g1 * c1 + g2 * c2 + gd * cd; TA[e] = t;
-    } else {
-      gB0[e] = g0; gB1[e] = g1; gB2[e] = g2; gBd[e] = gd;
-      gSB[e] = g0 * c0 + g1 * c1 + g2 * c2 + gd * cd; TB[e] = t;
-    }
+    gS[q] = g0[q] * c0 + g1[q] * c1 + g2[q] * c2 + gd[q] * cd;
   }
   // does any pixel of the tile reach this segment?
   int ml = max(max(last[0], last[1]), max(last[2], last[3]));
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) ml = max(ml, __shfl_xor(ml, off));
   if (base >= ml) {
-#pragma unroll
-    for (int h = 0; h < kStage; h++)
-      if (slot[h] >= 0) {
-        float4* dst = B.pair_grad + (size_t)slot[h] * 3;
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        dst[0] = z; dst[1] = z; dst[2] = z;
-      }
+    if (slot >= 0) {
+      float4* dst = B.pair_grad + (size_t)slot * 3;
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      dst[0] = z; dst[1] = z; dst[2] = z;
+    }
     return;
   }
   __syncthreads();
 
-  v2f JA[6], JB[6];   // sketch mode: per-pixel pose-Jacobian rows of this segment
+  float J[SKETCH ? 4 : 1][6];   // sketch mode: per-pixel pose-Jacobian rows of this segment
 #pragma unroll
-  for (int t = 0; t < 6; t++) { JA[t] = v2f{0.f, 0.f}; JB[t] = v2f{0.f, 0.f}; }
+  for (int q = 0; q < (SKETCH ? 4 : 1); q++)
+#pragma unroll
+    for (int t = 0; t < 6; t++) J[q][t] = 0.f;
   // reduce-scatter bookkeeping (wave_reduce.h): which of the ten sums this lane ends up with
   const unsigned long long b3mask = __ballot((lane & 8) != 0);
   const bool wextra = lane == 31 || lane == 63;
   const int wofs = wextra ? (lane == 31 ? 8 : 9)
                           : ((lane & 7) == 0 ? ((lane >> 5) & 1) + 2 * ((lane >> 4) & 1) + 4 * ((lane >> 3) & 1) : -1);
-  const float fpx = (float)px;
-  const v2f fpyA = {(float)pyb, (float)(pyb + 4)}, fpyB = {(float)(pyb + 8), (float)(pyb + 12)};
-  float4 u = s_r0[0], v = s_r1[0];
-  float2 cgb = s_r2[0];
+  const float fx[2] = {(float)qx, (float)(qx + 8)}, fy[2] = {(float)qy, (float)(qy + 8)};
+
   for (int j = 0; j < nb; j++) {
-    const int jn = min(j + 1, nb - 1);
-    const float4 un = s_r0[jn], vn = s_r1[jn];
-    const float2 cn = s_r2[jn];
+    // quadrants this splat can reach at all (exact bound, evaluated once by the staging lane)
+    const unsigned int m = __builtin_amdgcn_readfirstlane(s_mask[j]);
+    if (m == 0u) continue;
+    const float4 u = s_r0[j], v = s_r1[j];
+    const float2 cgb = s_r2[j];
     const int idx = base + j;
-    const float dx = u.x - fpx;
-    const float tA = u.z * dx;
-    const v2f dyA = v2f{u.y, u.y} - fpyA, dyB = v2f{u.y, u.y} - fpyB;
-    const v2f pwA = dx * (tA + u.w * dyA) + v.x * dyA * dyA;
-    const v2f pwB = dx * (tA + u.w * dyB) + v.x * dyB * dyB;
-    const v2f arA = v.y * v2f{__builtin_amdgcn_exp2f(pwA.x), __builtin_amdgcn_exp2f(pwA.y)};
-    const v2f arB = v.y * v2f{__builtin_amdgcn_exp2f(pwB.x), __builtin_amdgcn_exp2f(pwB.y)};
-    const v2f alA = v2f{fminf(kAlphaMax, arA.x), fminf(kAlphaMax, arA.y)};
-    const v2f alB = v2f{fminf(kAlphaMax, arB.x), fminf(kAlphaMax, arB.y)};
-    const bool k0 = idx < last[0] && pwA.x <= 0.f && alA.x >= kAlphaMin;
-    const bool k1 = idx < last[1] && pwA.y <= 0.f && alA.y >= kAlphaMin;
-    const bool k2 = idx < last[2] && pwB.x <= 0.f && alB.x >= kAlphaMin;
-    const bool k3 = idx < last[3] && pwB.y <= 0.f && alB.y >= kAlphaMin;
-    if (__ballot(k0 || k1 || k2 || k3) != 0ull) {
-      const v2f aeA = v2f{k0 ? alA.x : 0.f, k1 ? alA.y : 0.f};
-      const v2f aeB = v2f{k2 ? alB.x : 0.f, k3 ? alB.y : 0.f};
-      const v2f wA = aeA * TA, wB = aeB * TB;
-      // g . c (c is the splat's colour/depth, uniform over the wave)
-      const v2f gcA = gA0 * v.w + gA1 * cgb.x + gA2 * cgb.y + gAd * v.z;
-      const v2f gcB = gB0 * v.w + gB1 * cgb.x + gB2 * cgb.y + gBd * v.z;
-      gSA -= wA * gcA; gSB -= wB * gcB;
-      const v2f omA = 1.f - aeA, omB = 1.f - aeB;
-      const v2f roA = v2f{__builtin_amdgcn_rcpf(omA.x), __builtin_amdgcn_rcpf(omA.y)};
-      const v2f roB = v2f{__builtin_amdgcn_rcpf(omB.x), __builtin_amdgcn_rcpf(omB.y)};
-      const v2f dA = TA * gcA - roA * gSA, dB = TB * gcB - roB * gSB;
-      TA *= omA; TB *= omB;
-      v2f WA = arA * dA, WB = arB * dB;
-      WA = v2f{k0 ? WA.x : 0.f, k1 ? WA.y : 0.f};
-      WB = v2f{k2 ? WB.x : 0.f, k3 ? WB.y : 0.f};
-      const v2f WyA = WA * dyA, WyB = WB * dyB;
-      const v2f WyyA = WyA * dyA + WyB * dyB;
-      const v2f Ws2 = WA + WB, Sy2 = WyA + WyB;
-      const v2f r6 = wA * gA0 + wB * gB0, r7 = wA * gA1 + wB * gB1;
-      const v2f r8 = wA * gA2 + wB * gB2, r9 = wA * gAd + wB * gBd;
+    float r[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) r[i] = 0.f;
+    bool any = false;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (!(m & (1u << q))) continue;                 // wave-uniform
+      const float dx = u.x - fx[q & 1], dy = u.y - fy[q >> 1];
+      const float pw = dx * (u.z * dx + u.w * dy) + v.x * dy * dy;
+      const float ar = v.y * __builtin_amdgcn_exp2f(pw);
+      const float al = fminf(kAlphaMax, ar);
+      const bool k = idx < last[q] && pw <= 0.f && al >= kAlphaMin;
+      if (__ballot(k) == 0ull) continue;              // wave-uniform
+      any = true;
+      const float ae = k ? al : 0.f;
+      const float w = ae * T[q];
+      const float gc = g0[q] * v.w + g1[q] * cgb.x + g2[q] * cgb.y + gd[q] * v.z;   // g . c
+      gS[q] -= w * gc;
+      const float om = 1.f - ae;
+      const float ro = __builtin_amdgcn_rcpf(om);
+      const float dA = T[q] * gc - ro * gS[q];
+      T[q] *= om;
+      const float Wt = k ? ar * dA : 0.f;
+      const float Wx = Wt * dx, Wy = Wt * dy;
+      r[0] += Wt; r[1] += Wx; r[2] += Wy;
+      r[3] += Wx * dx; r[4] += Wx * dy; r[5] += Wy * dy;
+      r[6] += w * g0[q]; r[7] += w * g1[q]; r[8] += w * g2[q]; r[9] += w * gd[q];
       if constexpr (SKETCH) {
         // J_t += W (c0 dx + c1 dy + c2 dx^2 + c3 dx dy + c4 dy^2) + (w dL/dD) c5
-        const v2f XA1 = WA * dx, XB1 = WB * dx;
-        const v2f XA3 = XA1 * dx, XB3 = XB1 * dx, XA4 = XA1 * dyA, XB4 = XB1 * dyB;
-        const v2f XA5 = WyA * dyA, XB5 = WyB * dyB;
-        const v2f XA6 = wA * gAd, XB6 = wB * gBd;
+        const float X3 = Wx * dx, X4 = Wx * dy, X5 = Wy * dy, X6 = w * gd[q];
         const float* cf = reinterpret_cast<const float*>(&s_coef[j][0]);
 #pragma unroll
-        for (int t = 0; t < 6; t++) {
-          const float c0 = cf[6 * t], c1 = cf[6 * t + 1], c2 = cf[6 * t + 2], c3 = cf[6 * t + 3],
-                      c4 = cf[6 * t + 4], c5 = cf[6 * t + 5];
-          JA[t] += c0 * XA1 + c1 * WyA + c2 * XA3 + c3 * XA4 + c4 * XA5 + c5 * XA6;
-          JB[t] += c0 * XB1 + c1 * WyB + c2 * XB3 + c3 * XB4 + c4 * XB5 + c5 * XB6;
-        }
+        for (int t = 0; t < 6; t++)
+          J[q][t] += cf[6 * t] * Wx + cf[6 * t + 1] * Wy + cf[6 * t + 2] * X3 + cf[6 * t + 3] * X4 +
+                     cf[6 * t + 4] * X5 + cf[6 * t + 5] * X6;
       }
-      float r[10];
-      const float Ws = Ws2.x + Ws2.y, Sy = Sy2.x + Sy2.y;
-      r[0] = Ws; r[1] = Ws * dx; r[2] = Sy; r[3] = r[1] * dx; r[4] = Sy * dx;
-      r[5] = WyyA.x + WyyA.y;
-      r[6] = r6.x + r6.y; r[7] = r7.x + r7.y; r[8] = r8.x + r8.y; r[9] = r9.x + r9.y;
+    }
+    if (any) {
       float mres, eres;
       wave_sum10_scatter(r, b3mask, mres, eres);
       if (wofs >= 0) reinterpret_cast<float*>(&s_out[j][0])[wofs] = wextra ? eres : mres;
     }
-    u = un; v = vn; cgb = cn;
   }
   if constexpr (SKETCH) {
     // pixel rows of different segments of a tile meet in pix_jac: float atomics, planar
-    // [6][H*W] so a wave instruction covers 16-pixel runs of contiguous addresses
+    // [6][H*W] so a wave instruction covers 8-pixel runs of contiguous addresses
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const int py = pyb + 4 * q;
+      const int px = qx + 8 * (q & 1), py = qy + 8 * (q >> 1);
       if (px < P.W && py < P.H) {
         const size_t pix = (size_t)py * P.W + px;
 #pragma unroll
-        for (int t = 0; t < 6; t++) {
-          const float val = (q < 2) ? JA[t][q & 1] : JB[t][q & 1];
-          atomicAdd(&B.pix_jac[(size_t)t * HW + pix], val);
-        }
+        for (int t = 0; t < 6; t++) atomicAdd(&B.pix_jac[(size_t)t * HW + pix], J[q][t]);
       }
     }
   }
   __syncthreads();
-#pragma unroll
-  for (int h = 0; h < kStage; h++) {
-    if (slot[h] >= 0) {
-      const int jj = lane + 64 * h;
-      const float4 p0 = s_out[jj][0], p1 = s_out[jj][1], p2 = s_out[jj][2];
-      const float S1 = p0.x, Sx = p0.y, Sy = p0.z, Sxx = p0.w, Sxy = p1.x, Syy = p1.y;
-      const float A = qb[h].x, Bc = qb[h].y, Cc = qb[h].z, o = qa[h].w;
-      float4* dst = B.pair_grad + (size_t)slot[h] * 3;
-      dst[0] = make_float4(-(A * Sx + Bc * Sy), -(Cc * Sy + Bc * Sx), -0.5f * Sxx, -Sxy);
-      dst[1] = make_float4(-0.5f * Syy, S1 / o, p1.z, p1.w);
-      dst[2] = make_float4(p2.x, p2.y, 0.f, 0.f);
-    }
+  if (slot >= 0) {
+    const float4 p0 = s_out[lane][0], p1 = s_out[lane][1], p2 = s_out[lane][2];
+    const float S1 = p0.x, Sx = p0.y, Sy = p0.z, Sxx = p0.w, Sxy = p1.x, Syy = p1.y;
+    const float A = qb.x, Bc = qb.y, Cc = qb.z, o = qa.w;
+    float4* dst = B.pair_grad + (size_t)slot * 3;
+    dst[0] = make_float4(-(A * Sx + Bc * Sy), -(Cc * Sy + Bc * Sx), -0.5f * Sxx, -Sxy);
+    dst[1] = make_float4(-0.5f * Syy, S1 / o, p1.z, p1.w);
+    dst[2] = make_float4(p2.x, p2.y, 0.f, 0.f);
   }
 }
 
