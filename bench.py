@@ -261,6 +261,7 @@ def main():
         }
         print(json.dumps(out))
     if distributed:
+        dist.barrier()      # rank 0 has finished its (collective-free) profiling pass
         dist.destroy_process_group()
 
 

@@ -784,3 +784,48 @@ def test_inputs_without_grad_mixed_dtypes_and_mark_visible(built):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     vis = ras.markVisible(m)
     assert not vis[:50].any() and ((a[1] > 0) <= vis).all()
+
+
+def test_keyframe_insertion_on_device(built):
+    """back-projection + sub-sampling + knn scale initialisation without
+    leaving the GPU; checked through its invariants (reference: gaussian_model.py:131-205)."""
+    from monogs_amd import synthetic as S
+    from monogs_amd.keyframe_init import create_pcd_from_image_and_depth, monocular_depth_prior
+    from monogs_amd.pose import SE3_exp
+    from oracle import torch_raster as O
+    dev = _dev()
+    H, W = 120, 160
+    cam0 = S.make_camera(W, H)
+
+    class Cam:
+        pass
+
+    cam = Cam()
+    cam.fx, cam.fy, cam.cx, cam.cy = cam0.fx, cam0.fy, cam0.cx, cam0.cy
+    cam.T = SE3_exp(torch.tensor([0.2, -0.1, 0.3, 0.05, -0.02, 0.04])).to(dev)
+    cam.exposure_a, cam.exposure_b, cam.exposure_eps = torch.tensor([1.0], device=dev), torch.tensor([0.0], device=dev), 1e-8
+    g = torch.Generator(device=dev).manual_seed(0)
+    image = torch.rand(3, H, W, device=dev, generator=g)
+    depth = 1.0 + 3.0 * torch.rand(H, W, device=dev, generator=g)
+    depth[:10] = 0.0                                            # invalid rows are never used
+    xyz, feats, scales, rots, opac = create_pcd_from_image_and_depth(
+        cam, image, depth, downsample_factor=8, point_size=0.01, generator=g)
+    P = xyz.shape[0]
+    assert P == int((depth > 0).sum().item() / 8)
+    # every point re-projects onto an integer pixel with the depth it came from
+    pc = xyz @ cam.T[:3, :3].t() + cam.T[:3, 3]
+    u = pc[:, 0] / pc[:, 2] * cam.fx + cam.cx
+    v = pc[:, 1] / pc[:, 2] * cam.fy + cam.cy
+    assert (u - u.round()).abs().max() < 1e-2 and (v - v.round()).abs().max() < 1e-2
+    ui, vi = u.round().long(), v.round().long()
+    assert (vi >= 10).all()
+    assert torch.allclose(pc[:, 2], depth[vi, ui], rtol=1e-4)
+    # colours are the uint8-quantised image in SH-0 form; scales follow the knn rule
+    col = torch.floor(image[:, vi, ui].t() * 255) / 255
+    assert torch.allclose(feats[:, :, 0], (col - 0.5) / 0.28209479177387814, atol=1e-5)
+    ps = min(0.05, 0.01 * float(torch.median(depth)))
+    want = torch.log(torch.sqrt(torch.clamp_min(O.dist2_knn3(xyz.cpu()), 1e-7) * ps))
+    assert torch.allclose(scales[:, 0].cpu(), want, atol=1e-4)
+    assert (rots[:, 0] == 1).all() and (rots[:, 1:] == 0).all() and torch.allclose(torch.sigmoid(opac), torch.full_like(opac, 0.5))
+    d = monocular_depth_prior(H, W, 2.0, dev, g)
+    assert abs(d.mean().item() - 2.0 * (1 - 0.025)) < 0.01
