@@ -240,6 +240,10 @@ __global__ __launch_bounds__(64) void k_blend_bwd(KP P, KB B) {
       T[q] = ck[p]; c0 -= ck[256 + p]; c1 -= ck[512 + p]; c2 -= ck[768 + p]; cd -= ck[1024 + p];
     }
     gS[q] = g0[q] * c0 + g1[q] * c1 + g2[q] * c2 + gd[q] * cd;
+    // a pixel whose list ended in front of this segment contributes nothing here, and the
+    // forward stops checkpointing a quadrant once all its pixels are saturated: never let
+    // that (unwritten) state into the arithmetic
+    if (last[q] <= base) { T[q] = 0.f; gS[q] = 0.f; }
   }
   // does any pixel of the tile reach this segment?
   int ml = max(max(last[0], last[1]), max(last[2], last[3]));

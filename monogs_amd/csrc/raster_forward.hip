@@ -488,32 +488,50 @@ __global__ __launch_bounds__(256) void k_tile_sort(KP P) {
 }
 
 // ---------------------------------------------------------------------------------
-// Front-to-back blend.  256 threads = one 16x16 tile; wave w owns the 8x8 QUADRANT
-// (w & 1, w >> 1) of the tile, one pixel per lane.  The tile's sorted splat list is staged
-// through LDS 256 records at a time; the staging thread pre-multiplies the conic by
-// -0.5*log2(e) (a pixel evaluation is a few FMAs + one v_exp_f32) and tests which of the
-// four quadrants its splat can reach at all (same closed-form bound as the tile culling,
-// on the 8x8 pixel box).  Each wave then walks only the splats whose bit is set for its
-// quadrant (ballot mask, scalar bit scan): for splats of a few pixels' extent about half
-// of the (wave, splat) evaluations disappear, and a tile's serial chain is split over four
-// independent waves instead of two.  Skipping is exact: a skipped splat has alpha < 1/255
-// on all 64 pixels.  Every kSeg splats the per-pixel blend state (T, C, D) is
-// checkpointed for the segment-parallel backward.
+// Front-to-back blend.  One WAVE per 8x8 quadrant of a tile (one pixel per lane), launched
+// as its own 64-thread workgroup: the four quadrant waves of a tile are fully independent,
+// so there is no workgroup barrier anywhere, a saturated quadrant retires at once, and the
+// dispatcher balances 4T equal-shaped items instead of T ragged ones.  (A CU admits
+// workgroups only up to 64 KB of LDS in total - measured with in-kernel stamps: the former
+// 256-thread / 13.5 KB form ran 4 deep per CU and the last 176 tiles started 50 us late -
+// this form needs 2.5 KB.)
+//
+// The wave walks the tile's sorted list 64 splats (one segment) at a time: lane l loads
+// splat l's record and tests whether the splat can reach THIS quadrant at all (closed-form
+// bound of the tile culling on the 8x8 pixel box - exact: a skipped splat has alpha < 1/255
+// on all 64 pixels); reachable splats are parked in LDS with the conic pre-multiplied by
+// -0.5*log2(e) (a pixel evaluation is a few FMAs + one v_exp_f32) and the wave visits them
+// in list order by scanning the ballot mask.  Global loads are software-pipelined: ids two
+// segments ahead, records one segment ahead, so the id -> record dependent latency hides
+// under the previous segment's arithmetic.  In front of every segment the per-pixel blend
+// state (T, C, D) is checkpointed for the segment-parallel backward; a quadrant whose
+// pixels are all saturated stops writing checkpoints (the backward never reads the state
+// of a pixel whose n_contrib lies in front of the segment).
 constexpr float kLog2e = 1.4426950408889634f;
-constexpr int kFwdThreads = 256;
-constexpr int kFwdStage = 256;     // records staged per batch
-static_assert(kFwdStage % kSeg == 0 && kSeg == 64, "a batch is a whole number of 64-splat segments");
+typedef float v2f __attribute__((ext_vector_type(2)));
+constexpr int kFwdChunk = 4;       // the four quadrants of a tile share an XCD (same records)
+static_assert(kSeg == 64, "one staged record per lane");
 
-__global__ __launch_bounds__(kFwdThreads) void k_blend_fwd(KP P) {
-  __shared__ float4 s_r0[kFwdStage], s_r1[kFwdStage];
-  __shared__ float2 s_r2[kFwdStage];
-  __shared__ unsigned int s_id[kFwdStage];
-  __shared__ unsigned int s_mask[kFwdStage];
-  __shared__ int s_cnt[kFwdStage];
-  const int tile = blockIdx.x;   // (an XCD-chunked order was measured: no gain for the forward)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ unsigned int fwd_load_id(const KP& P, int start, int n, int k) {
+  // low half of the 64-bit key = Gaussian id
+  return k < n ? reinterpret_cast<const unsigned int*>(P.keys + start)[2 * (size_t)k] : 0u;
+}
+
+// m &= ~(1 << j) on a wave-uniform 64-bit mask in ONE scalar instruction (the C form
+// m &= m - 1 costs s_add_u32 + s_addc_u32 + s_and_b64).
+__device__ __forceinline__ void mask_clear_bit(unsigned long long& m, int j) {
+  asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(j));
+}
+
+__global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
+  // per staged splat 48 B: (x, y, A', B') (C', opacity, r, g) (b, depth, -, -)
+  __shared__ float4 s_rec[kSeg * 3];
+  const int item = xcd_remap<kFwdChunk>(blockIdx.x);
+  if (item >= 4 * P.T) return;
+  const int tile = item >> 2, quad = item & 3, lane = threadIdx.x;
   const int tx = tile % P.grid_x, ty = tile / P.grid_x;
-  const int qx0 = tx * kTile + 8 * (wave & 1), qy0 = ty * kTile + 8 * (wave >> 1);
+  const int qx0 = tx * kTile + 8 * (quad & 1), qy0 = ty * kTile + 8 * (quad >> 1);
+  if (qx0 >= P.W || qy0 >= P.H) return;                  // quadrant outside the image
   const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
   const int ptile = (py - ty * kTile) * kTile + (px - tx * kTile);     // pixel index in the tile
   const bool inside = px < P.W && py < P.H;
@@ -521,57 +539,52 @@ __global__ __launch_bounds__(kFwdThreads) void k_blend_fwd(KP P) {
   start = min(start, P.cap); end = min(end, P.cap);
   const int n = end - start;
   const int seg0 = P.seg_offset[tile];
-  // quadrant boxes (pixel centres, clipped to the image) for the staging thread's test
-  const float bx0 = (float)(tx * kTile), by0 = (float)(ty * kTile);
-  const float Wm = (float)(P.W - 1), Hm = (float)(P.H - 1);
+  // this quadrant's pixel-centre box, clipped to the image
+  const float bx0 = (float)qx0, by0 = (float)qy0;
+  const float bx1 = fminf(bx0 + 7.f, (float)(P.W - 1)), by1 = fminf(by0 + 7.f, (float)(P.H - 1));
   float live = inside ? 1.f : 0.f;
-  float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
+  float T = 1.f;
+  v2f C01 = {0.f, 0.f}, C2D = {0.f, 0.f};     // (C0, C1), (C2, depth): packed-FMA operands
   int last = 0;
   const float fpx = (float)px, fpy = (float)py;
-  for (int base = 0; base < n; base += kFwdStage) {
-    if (__syncthreads_count(live == 0.f) == kFwdThreads) break;
-    const int nb = min(kFwdStage, n - base);
-    unsigned int mask4 = 0;
-    if (tid < nb) {
-      const unsigned int id = (unsigned int)P.keys[start + base + tid];
-      const float4* src = reinterpret_cast<const float4*>(P.rec + id);
-      const float4 a = src[0], b = src[1], c = src[2];
-      // (x, y, A', B') (C', opacity, depth, r) (g, b)
-      s_r0[tid] = make_float4(a.x, a.y, -0.5f * kLog2e * b.x, -kLog2e * b.y);
-      s_r1[tid] = make_float4(-0.5f * kLog2e * b.z, a.w, a.z, c.x);
-      s_r2[tid] = make_float2(c.y, c.z);
-      s_id[tid] = id;
-      const float qmax = splat_qmax(a.w);
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const float x0 = bx0 + 8.f * (q & 1), y0 = by0 + 8.f * (q >> 1);
-        if (x0 <= Wm && y0 <= Hm &&
-            box_reachable(a.x, a.y, b.x, b.y, b.z, qmax, x0, y0, fminf(x0 + 7.f, Wm), fminf(y0 + 7.f, Hm)))
-          mask4 |= 1u << q;
+
+  // pipeline prologue: ids of segments 0 and 1, records of segment 0
+  // (ids default to 0, a valid record, so the record loads need no branch)
+  unsigned int id_n1 = fwd_load_id(P, start, n, kSeg + lane);
+  unsigned int cid = fwd_load_id(P, start, n, lane);
+  const float4* src0 = reinterpret_cast<const float4*>(P.rec + cid);
+  float4 ca = src0[0], cb = src0[1], cc = src0[2];
+
+  for (int base = 0; base < n; base += kSeg) {
+    // issue the loads of the NEXT segment before touching this one
+    const unsigned int nid = id_n1;
+    const float4* src1 = reinterpret_cast<const float4*>(P.rec + nid);
+    const float4 na = src1[0], nb4 = src1[1], nc = src1[2];
+    id_n1 = fwd_load_id(P, start, n, base + 2 * kSeg + lane);
+
+    if (base > 0) {   // checkpoint: state in front of this segment
+      const int sg = seg0 + base / kSeg;
+      if (sg < P.max_segs) {
+        float* ck = P.ckpt + (size_t)sg * (5 * 256) + ptile;
+        ck[0] = T; ck[256] = C01.x; ck[512] = C01.y; ck[768] = C2D.x; ck[1024] = C2D.y;
       }
     }
-    s_mask[tid] = mask4;
-    s_cnt[tid] = 0;
-    __syncthreads();
-    for (int cb = 0; cb < nb; cb += kSeg) {
-      if (base + cb > 0) {   // checkpoint: state in front of this segment
-        const int sg = seg0 + (base + cb) / kSeg;
-        if (sg < P.max_segs) {
-          float* ck = P.ckpt + (size_t)sg * (5 * 256) + ptile;
-          ck[0] = T; ck[256] = C0; ck[512] = C1; ck[768] = C2; ck[1024] = D;
-        }
+    const bool reach = base + lane < n &&
+                       box_reachable(ca.x, ca.y, cb.x, cb.y, cb.z, splat_qmax(ca.w), bx0, by0, bx1, by1);
+    unsigned long long m = __builtin_amdgcn_ballot_w64(reach);
+    int touched = 0;
+    if (m != 0ull) {
+      __syncthreads();   // single-wave workgroup: orders the LDS traffic, no hardware barrier
+      if (reach) {
+        s_rec[3 * lane] = make_float4(ca.x, ca.y, -0.5f * kLog2e * cb.x, -kLog2e * cb.y);
+        s_rec[3 * lane + 1] = make_float4(-0.5f * kLog2e * cb.z, ca.w, cc.x, cc.y);
+        s_rec[3 * lane + 2] = make_float4(cc.z, ca.z, 0.f, 0.f);
       }
-      if (__builtin_amdgcn_ballot_w64(live != 0.f) == 0ull) continue;   // quadrant saturated
-      unsigned long long m = __builtin_amdgcn_ballot_w64(((s_mask[cb + lane] >> wave) & 1u) != 0);
-      if (m == 0ull) continue;
-      int j = cb + __builtin_ctzll(m);
-      float4 u = s_r0[j], v = s_r1[j];
-      float2 cgb = s_r2[j];
-      while (true) {
-        m &= m - 1ull;
-        const int jn = m ? cb + __builtin_ctzll(m) : j;
-        const float4 un = s_r0[jn], vn = s_r1[jn];     // prefetch the next splat of this quadrant
-        const float2 cn = s_r2[jn];
+      __syncthreads();
+      // n_touched only counts contributions made while T(1-alpha) > 0.5: once no pixel of the
+      // quadrant is that transparent any more the counting code is skipped (wave-uniform)
+      const bool count_touch = __builtin_amdgcn_ballot_w64(T > kTouchT && live != 0.f) != 0ull;
+      auto visit = [&](int j, const float4 u, const float4 v, const float2 bd) {
         const float dx = u.x - fpx, dy = u.y - fpy;
         const float pw = dx * (u.z * dx + u.w * dy) + v.x * dy * dy;
         const float araw = v.y * __builtin_amdgcn_exp2f(pw);
@@ -584,29 +597,52 @@ __global__ __launch_bounds__(kFwdThreads) void k_blend_fwd(KP P) {
         live = stop ? 0.f : live;
         a = stop ? 0.f : a;
         const float w = a * T;
-        C0 += v.w * w; C1 += cgb.x * w; C2 += cgb.y * w; D += v.z * w;
+        const v2f ww = {w, w};
+        const v2f rg = {v.z, v.w}, bdv = {bd.x, bd.y};
+        C01 = __builtin_elementwise_fma(rg, ww, C01);
+        C2D = __builtin_elementwise_fma(bdv, ww, C2D);
         T = stop ? T : test_T;
         last = a > 0.f ? (base + j + 1) : last;
-        const unsigned long long tm = __builtin_amdgcn_ballot_w64(a > 0.f && test_T > kTouchT);
-        if (tm != 0ull && lane == 0) atomicAdd(&s_cnt[j], __popcll(tm));
+        if (count_touch) {
+          const unsigned long long tm = __builtin_amdgcn_ballot_w64(a > 0.f && test_T > kTouchT);
+          if (tm != 0ull) touched += lane == j ? __popcll(tm) : 0;
+        }
+      };
+      // two-way unrolled walk over the set bits of m: splat j in (u0, v0, w0), the next one
+      // is prefetched into (u1, v1, w1) and vice versa, so no registers are rotated
+      int j0 = __builtin_ctzll(m);
+      float4 u0 = s_rec[3 * j0], v0 = s_rec[3 * j0 + 1];
+      float2 w0 = *reinterpret_cast<const float2*>(&s_rec[3 * j0 + 2]);
+      while (true) {
+        mask_clear_bit(m, j0);
+        const int j1 = __builtin_ctzll(m) & 63;       // m == 0: harmless read of slot 63
+        const float4 u1 = s_rec[3 * j1], v1 = s_rec[3 * j1 + 1];
+        const float2 w1 = *reinterpret_cast<const float2*>(&s_rec[3 * j1 + 2]);
+        visit(j0, u0, v0, w0);
         if (m == 0ull) break;
-        j = jn; u = un; v = vn; cgb = cn;
+        mask_clear_bit(m, j1);
+        j0 = __builtin_ctzll(m) & 63;
+        u0 = s_rec[3 * j0]; v0 = s_rec[3 * j0 + 1];
+        w0 = *reinterpret_cast<const float2*>(&s_rec[3 * j0 + 2]);
+        visit(j1, u1, v1, w1);
+        if (m == 0ull) break;
       }
     }
-    __syncthreads();
-    if (tid < nb && s_cnt[tid] > 0) atomicAdd(&P.n_touched[s_id[tid]], s_cnt[tid]);
+    if (touched > 0) atomicAdd(&P.n_touched[cid], touched);
+    if (__builtin_amdgcn_ballot_w64(live != 0.f) == 0ull) break;   // quadrant saturated
+    cid = nid; ca = na; cb = nb4; cc = nc;
   }
   if (inside) {
     const size_t HW = (size_t)P.W * P.H;
     const size_t pix = (size_t)py * P.W + px;
     P.final_T[pix] = T;
     P.n_contrib[pix] = last;
-    P.final_C[pix] = C0; P.final_C[HW + pix] = C1;
-    P.final_C[2 * HW + pix] = C2; P.final_C[3 * HW + pix] = D;
-    P.out_color[pix] = C0 + T * P.bg[0];
-    P.out_color[HW + pix] = C1 + T * P.bg[1];
-    P.out_color[2 * HW + pix] = C2 + T * P.bg[2];
-    P.out_depth[pix] = D;
+    P.final_C[pix] = C01.x; P.final_C[HW + pix] = C01.y;
+    P.final_C[2 * HW + pix] = C2D.x; P.final_C[3 * HW + pix] = C2D.y;
+    P.out_color[pix] = C01.x + T * P.bg[0];
+    P.out_color[HW + pix] = C01.y + T * P.bg[1];
+    P.out_color[2 * HW + pix] = C2D.x + T * P.bg[2];
+    P.out_depth[pix] = C2D.y;
     P.out_opacity[pix] = 1.f - T;
   }
 }
@@ -653,7 +689,7 @@ int launch_forward_blend(const KP& P, hipStream_t st) {
   }
   launch("tile_sort", k_tile_sort<1024, 0>, dim3(P.T), dim3(256), st, P);
   launch("tile_sort_big", k_tile_sort<4096, 1024>, dim3(P.T), dim3(256), st, P);
-  launch("blend_fwd", k_blend_fwd, dim3(P.T), dim3(kFwdThreads), st, P);
+  launch("blend_fwd", k_blend_fwd, dim3(grid_pad(4 * P.T, kFwdChunk)), dim3(64), st, P);
   return check_launch();
 }
 
