@@ -152,12 +152,11 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr float kLog2eB = 1.4426950408889634f;
 
 template <bool SKETCH>
-__global__ __launch_bounds__(64) void k_blend_bwd(KP P, KB B) {
+__global__ __launch_bounds__(64, 6) void k_blend_bwd(KP P, KB B) {
   static_assert(kSeg == 64, "one staged record per lane");
   __shared__ float4 s_r0[kSeg], s_r1[kSeg];
   __shared__ float2 s_r2[kSeg];
   __shared__ unsigned int s_mask[kSeg];
-  __shared__ float4 s_out[kSeg][3];
   __shared__ float4 s_coef[SKETCH ? kSeg : 1][9];   // per splat: 6 tau components x 6 coefficients
   const int item = xcd_remap<kBwdChunk>(blockIdx.x), lane = threadIdx.x;
   if (item >= min(P.seg_offset[P.T], P.max_segs)) return;
@@ -175,7 +174,6 @@ __global__ __launch_bounds__(64) void k_blend_bwd(KP P, KB B) {
 
   // ---- stage the segment's records (one per lane): slot, raw conic, quadrant reach mask ---
   int slot = -1;
-  float4 qa, qb;
   {
     unsigned int mask4 = 0;
     if (lane < nb) {
@@ -183,7 +181,7 @@ __global__ __launch_bounds__(64) void k_blend_bwd(KP P, KB B) {
       const unsigned int id = (unsigned int)P.keys[k];
       slot = pair_slot_base(P, (int)id) + (int)P.payload[k];
       const float4* src = reinterpret_cast<const float4*>(P.rec + id);
-      qa = src[0]; qb = src[1];
+      const float4 qa = src[0], qb = src[1];
       const float4 q2 = src[2];
       s_r0[lane] = make_float4(qa.x, qa.y, -0.5f * kLog2eB * qb.x, -kLog2eB * qb.y);
       s_r1[lane] = make_float4(-0.5f * kLog2eB * qb.z, qa.w, qa.z, q2.x);
@@ -204,8 +202,6 @@ __global__ __launch_bounds__(64) void k_blend_bwd(KP P, KB B) {
       }
     }
     s_mask[lane] = mask4;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    s_out[lane][0] = z; s_out[lane][1] = z; s_out[lane][2] = z;
   }
 
   // ---- per-pixel state ----------------------------------------------------------------------
@@ -271,6 +267,7 @@ __global__ __launch_bounds__(64) void k_blend_bwd(KP P, KB B) {
                           : ((lane & 7) == 0 ? ((lane >> 5) & 1) + 2 * ((lane >> 4) & 1) + 4 * ((lane >> 3) & 1) : -1);
   const float fx[2] = {(float)qx, (float)(qx + 8)}, fy[2] = {(float)qy, (float)(qy + 8)};
 
+  unsigned long long written = 0ull;
   for (int j = 0; j < nb; j++) {
     // quadrants this splat can reach at all (exact bound, evaluated once by the staging lane)
     const unsigned int m = __builtin_amdgcn_readfirstlane(s_mask[j]);
@@ -316,9 +313,13 @@ __global__ __launch_bounds__(64) void k_blend_bwd(KP P, KB B) {
       }
     }
     if (any) {
+      // the ten wave totals land in ten different lanes; each stores its own dword of the
+      // pair's record (slot of splat j broadcast from lane j): one store instruction per splat
       float mres, eres;
       wave_sum10_scatter(r, b3mask, mres, eres);
-      if (wofs >= 0) reinterpret_cast<float*>(&s_out[j][0])[wofs] = wextra ? eres : mres;
+      float* dst = reinterpret_cast<float*>(B.pair_grad) + (size_t)__builtin_amdgcn_readlane(slot, j) * 12;
+      if (wofs >= 0) dst[wofs] = wextra ? eres : mres;
+      written |= 1ull << j;
     }
   }
   if constexpr (SKETCH) {
@@ -334,15 +335,11 @@ __global__ __launch_bounds__(64) void k_blend_bwd(KP P, KB B) {
       }
     }
   }
-  __syncthreads();
-  if (slot >= 0) {
-    const float4 p0 = s_out[lane][0], p1 = s_out[lane][1], p2 = s_out[lane][2];
-    const float S1 = p0.x, Sx = p0.y, Sy = p0.z, Sxx = p0.w, Sxy = p1.x, Syy = p1.y;
-    const float A = qb.x, Bc = qb.y, Cc = qb.z, o = qa.w;
+  // splats of the segment that no pixel reached: zero record
+  if (slot >= 0 && !((written >> lane) & 1ull)) {
     float4* dst = B.pair_grad + (size_t)slot * 3;
-    dst[0] = make_float4(-(A * Sx + Bc * Sy), -(Cc * Sy + Bc * Sx), -0.5f * Sxx, -Sxy);
-    dst[1] = make_float4(-0.5f * Syy, S1 / o, p1.z, p1.w);
-    dst[2] = make_float4(p2.x, p2.y, 0.f, 0.f);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    dst[0] = z; dst[1] = z; dst[2] = z;
   }
 }
 
@@ -454,21 +451,27 @@ __global__ __launch_bounds__(kPreBlock) void k_preprocess_bwd(KP P, KB B) {
         a[4] += y.x; a[5] += y.y; a[6] += y.z; a[7] += y.w;
         a[8] += z.x; a[9] += z.y;
       }
+      // a[] = raw pixel sums (S1, Sx, Sy, Sxx, Sxy, Syy, Rr, Rg, Rb, Rd) over all tiles of
+      // the Gaussian; the conic / opacity are per-Gaussian, so the linear map to screen-space
+      // gradients is applied once here instead of once per pair
+      const float4 r0 = reinterpret_cast<const float4*>(P.rec + idx)[0];
+      const float cA = r1.x, cB = r1.y, cC = r1.z;
+      const float g_xy[2] = {-(cA * a[1] + cB * a[2]), -(cC * a[2] + cB * a[1])};
+      const float g_con[3] = {-0.5f * a[3], -a[4], -0.5f * a[5]};
+      const float g_op = a[0] != 0.f ? a[0] / r0.w : 0.f;   // opacity 0 never reaches a pixel
       Camera cam;
       load_camera_b(cam, P);
-      const float g_xy[2] = {a[0], a[1]};
-      const float g_con[3] = {a[2], a[3], a[4]};
       GaussGrad gg;
       if (P.covp) {
         float c6[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) c6[i] = P.covp[6 * (size_t)idx + i];
-        project_gaussian_backward(cam, p, nullptr, nullptr, c6, g_xy, g_con, a[5], a[9], gg);
+        project_gaussian_backward(cam, p, nullptr, nullptr, c6, g_xy, g_con, g_op, a[9], gg);
       } else {
         const float sc[3] = {P.scales[3 * idx], P.scales[3 * idx + 1], P.scales[3 * idx + 2]};
         const float4 qq = reinterpret_cast<const float4*>(P.rots)[idx];
         const float q[4] = {qq.x, qq.y, qq.z, qq.w};
-        project_gaussian_backward(cam, p, sc, q, nullptr, g_xy, g_con, a[5], a[9], gg);
+        project_gaussian_backward(cam, p, sc, q, nullptr, g_xy, g_con, g_op, a[9], gg);
       }
 #pragma unroll
       for (int i = 0; i < 3; i++) { dmean[i] = gg.dmean[i]; dscale[i] = gg.dscale[i]; grgb[i] = a[6 + i]; }
