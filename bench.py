@@ -70,7 +70,9 @@ def bench_tracking(sc, dev, iters):
     with torch.no_grad():
         target = render(view(torch.eye(4)), gauss, Pipe, bg)["render"].clone()
     out = {}
-    for mode in ("first_order", "first_order_fused", "second_order", "second_order_fused"):
+    from monogs_amd.tracking_native import NativeTracker
+    for mode in ("first_order", "first_order_fused", "first_order_native", "second_order",
+                 "second_order_fused"):
         vp = view(SE3_exp(torch.tensor([0.01, -0.008, 0.006, 0.002, -0.003, 0.002])))
         vp.original_image = target
         vp.rgb_pixel_mask_mapping = (target.sum(0) > 0.01).view(1, H, W)
@@ -78,12 +80,17 @@ def bench_tracking(sc, dev, iters):
         fopt = FusedPoseOptimizer(vp)
         gen = torch.Generator(device=dev).manual_seed(0)
         n = iters if mode.startswith("first") else max(10, iters // 4)
+        if mode == "first_order_native":
+            n = 4 * iters
+            trk = NativeTracker(vp, gauss, bg)
 
         def it():
             if mode == "first_order":
                 tracking_step_first_order(vp, gauss, opt, bg)
             elif mode == "first_order_fused":
                 tracking_step_first_order_fused(vp, gauss, fopt, bg)
+            elif mode == "first_order_native":
+                trk.step()
             else:
                 tracking_step_second_order(vp, gauss, bg, lambda_=1e-3, repeat_dim=1, stack_dim=16,
                                            sketch_dim=64, generator=gen,
@@ -96,6 +103,8 @@ def bench_tracking(sc, dev, iters):
             it()
         torch.cuda.synchronize()
         out[mode + "_iters_per_s"] = round(n / (time.perf_counter() - t0), 2)
+        if mode == "first_order_native" and not trk.check_capacity():
+            raise RuntimeError("native tracking bench overflowed its pair capacity")
     out["map"] = f"frozen SYN-C map, {sc.means3D.shape[0]} Gaussians @ {W}x{H}"
     return out
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MGS_ABI_VERSION 1
+#define MGS_ABI_VERSION 2
 
 typedef enum mgs_status {
   MGS_OK = 0,
@@ -102,7 +102,9 @@ typedef struct mgs_backward_args {
   const float* grad_color;     /* [3,H,W] */
   const float* grad_depth;     /* [1,H,W] or NULL */
   void* bwd;                   /* bwd_bytes of scratch */
-  /* outputs (all overwritten) */
+  /* outputs (all overwritten).  The per-Gaussian gradients (means3D, means2D, colors,
+   * opacities, scales, rotations, cov3D) may ALL be NULL: pose-only backward (tracking
+   * optimises the camera alone, utils/slam_frontend.py:364-392), grad_tau is still produced. */
   float* grad_means3D;         /* [N,3] */
   float* grad_means2D;         /* [N,3]: (dL/dndc_x, dL/dndc_y, 0) - densification statistic,
                                   gaussian_model.py:693-697 */
@@ -251,6 +253,39 @@ typedef struct mgs_tracking_loss_args {
 int32_t mgs_tracking_loss_partial_count(int64_t num_pixels);
 int32_t mgs_tracking_loss_forward(const mgs_tracking_loss_args* args, void* stream);
 int32_t mgs_tracking_loss_backward(const mgs_tracking_loss_args* args, void* stream);
+
+
+/* ---- native tracking iteration (row a12: utils/slam_frontend.py:493-630) ---------------- */
+
+/* Camera matrices of utils/camera_utils.py:94-108 from the world-to-camera pose:
+ * viewmatrix = T^T, projmatrix = viewmatrix @ projection (projection as stored by the
+ * reference, i.e. already transposed, camera_utils.py:86-89).  campos is the reference's
+ * camera_center, which IS world_view_transform (:106-108): pass the viewmatrix buffer. */
+int32_t mgs_camera_from_pose(const float* T, const float* projection, float* viewmatrix,
+                             float* projmatrix, void* stream);
+
+/* One first-order monocular tracking iteration, enqueued as a fixed launch sequence with
+ * no host round trip (the Python loop body costs ~1 ms of host time per iteration):
+ *   camera matrices from T -> rasteriser forward (project + blend at the caller's fixed
+ *   pair capacity) -> tracking objective (mgs_tracking_loss_*) -> pose-only rasteriser
+ *   backward -> Adam on (rot, trans, exposure a, b) + update_pose (mgs_pose_adam_step).
+ * fwd.viewmatrix / fwd.projmatrix / fwd.campos must point at caller-owned device buffers
+ * (16/16/>=3 floats; campos may alias viewmatrix) that this call REWRITES from T;
+ * fwd.projmatrix_raw is the projection.  The forward is complete iff counters[0] (pair
+ * count D, in geom) <= shape.pair_capacity: the caller checks that lazily.  Per-iteration
+ * results: loss_scalars[0] = loss, *adam.converged, the updated T / exposure. */
+typedef struct mgs_tracking_iter_args {
+  mgs_forward_args fwd;
+  void* bwd;                  /* bwd_bytes of backward scratch */
+  float* grad_image;          /* [3,H,W] scratch: dL/d(render) */
+  float* grad_tau;            /* [6] scratch: [rho; theta] */
+  float* grad_exposure;       /* [2] scratch: d/da, d/db */
+  const float* one;           /* [1] = 1.0f (dL/dloss) */
+  mgs_tracking_loss_args loss;   /* image/opacity/grad_* fields are filled in by the call */
+  mgs_pose_adam_args adam;       /* grad_* fields are filled in by the call; T must be set */
+} mgs_tracking_iter_args;
+
+int32_t mgs_tracking_iteration(const mgs_tracking_iter_args* args, void* stream);
 
 /* Per-kernel timing (diagnostics; used by bench.py for the roofline line).  While
  * enabled every kernel launch is bracketed by hipEvents on the launch stream.

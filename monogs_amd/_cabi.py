@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmonogs_raster.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 EXPORTS = (
     "mgs_abi_version", "mgs_status_string", "mgs_raster_workspace_query",
@@ -20,7 +20,7 @@ EXPORTS = (
     "mgs_knn_scratch_bytes", "mgs_knn_dist2", "mgs_profile_enable", "mgs_profile_read",
     "mgs_pose_adam_step", "mgs_tracking_loss_partial_count", "mgs_tracking_loss_forward",
     "mgs_tracking_loss_backward", "mgs_lm_solve_step", "mgs_mapping_loss_forward",
-    "mgs_mapping_loss_backward",
+    "mgs_mapping_loss_backward", "mgs_camera_from_pose", "mgs_tracking_iteration",
 )
 
 _fp = C.c_void_p  # device pointers travel as plain addresses
@@ -83,6 +83,12 @@ class TrackingLossArgs(C.Structure):
                 + [(n, _fp) for n in ("partial", "scalars", "grad_out", "grad_image", "grad_a", "grad_b")])
 
 
+class TrackingIterArgs(C.Structure):
+    _fields_ = [("fwd", ForwardArgs), ("bwd", _fp), ("grad_image", _fp), ("grad_tau", _fp),
+                ("grad_exposure", _fp), ("one", _fp), ("loss", TrackingLossArgs),
+                ("adam", PoseAdamArgs)]
+
+
 _lib = None
 
 
@@ -103,6 +109,10 @@ def lib():
     for name in EXPORTS:
         if not hasattr(L, name):
             raise NativeLibraryError(f"{LIB_PATH} does not export {name}")
+    L.mgs_camera_from_pose.restype = C.c_int32
+    L.mgs_camera_from_pose.argtypes = [C.c_void_p] * 5
+    L.mgs_tracking_iteration.restype = C.c_int32
+    L.mgs_tracking_iteration.argtypes = [C.POINTER(TrackingIterArgs), C.c_void_p]
     L.mgs_abi_version.restype = C.c_int32
     L.mgs_status_string.restype = C.c_char_p
     L.mgs_status_string.argtypes = [C.c_int32]

@@ -482,6 +482,7 @@ __global__ __launch_bounds__(kPreBlock) void k_preprocess_bwd(KP P, KB B) {
       dndc[0] = gg.dndc[0]; dndc[1] = gg.dndc[1];
       dop = gg.dop;
     }
+    if (B.g_means3D) {   // NULL: pose-only backward (tracking), nothing per Gaussian is stored
     // colours
     if (P.shs) {
       float* dsh = B.g_colors + (size_t)3 * P.K * idx;
@@ -507,6 +508,7 @@ __global__ __launch_bounds__(kPreBlock) void k_preprocess_bwd(KP P, KB B) {
     if (B.g_cov) {
 #pragma unroll
       for (int i = 0; i < 6; i++) B.g_cov[6 * (size_t)idx + i] = dcov[i];
+    }
     }
   }
   // block reduction of the pose gradient (fixed order -> deterministic)

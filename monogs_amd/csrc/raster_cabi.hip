@@ -139,9 +139,14 @@ int32_t mgs_raster_backward(const mgs_backward_args* args, void* stream) {
   KP P;
   const int rc = fill_kp(args->fwd, true, false, P);
   if (rc != MGS_OK) return rc;
-  if (!args->grad_color || !args->bwd || !args->grad_means3D || !args->grad_means2D ||
-      !args->grad_colors || !args->grad_opacities || !args->grad_tau)
-    return MGS_ERR_BAD_ARGUMENT;
+  if (!args->grad_color || !args->bwd || !args->grad_tau) return MGS_ERR_BAD_ARGUMENT;
+  {   // per-Gaussian gradients: all of the mandatory four, or none at all (pose-only)
+    const int have = (args->grad_means3D != nullptr) + (args->grad_means2D != nullptr) +
+                     (args->grad_colors != nullptr) + (args->grad_opacities != nullptr);
+    if (have != 0 && have != 4) return MGS_ERR_BAD_ARGUMENT;
+    if (have == 0 && (args->grad_scales || args->grad_rotations || args->grad_cov3D))
+      return MGS_ERR_BAD_ARGUMENT;
+  }
   if (args->sketch_mode != 0 &&
       (!args->sketch_indices || !args->grad_sketch_dtau || !args->sketch_ws ||
        args->sketch_dim < 1 || args->stack_dim < 1))
@@ -162,6 +167,37 @@ int32_t mgs_raster_backward(const mgs_backward_args* args, void* stream) {
   B.pix_jac = sw ? (float*)(sw + L.pix_jac) : nullptr;
   B.splat_jac = sw ? (float*)(sw + L.splat_jac) : nullptr;
   return launch_backward(P, B, (hipStream_t)stream);
+}
+
+int32_t mgs_tracking_iteration(const mgs_tracking_iter_args* args, void* stream) {
+  if (!args || !args->bwd || !args->grad_image || !args->grad_tau || !args->grad_exposure ||
+      !args->one || !args->adam.T || !args->fwd.viewmatrix || !args->fwd.projmatrix)
+    return MGS_ERR_BAD_ARGUMENT;
+  if (args->fwd.shape.pair_capacity < 1) return MGS_ERR_BAD_ARGUMENT;
+  int32_t rc = mgs_camera_from_pose(args->adam.T, args->fwd.projmatrix_raw,
+                                    const_cast<float*>(args->fwd.viewmatrix),
+                                    const_cast<float*>(args->fwd.projmatrix), stream);
+  if (rc != MGS_OK) return rc;
+  if ((rc = mgs_raster_forward_project(&args->fwd, stream)) != MGS_OK) return rc;
+  if ((rc = mgs_raster_forward_blend(&args->fwd, stream)) != MGS_OK) return rc;
+  mgs_tracking_loss_args L = args->loss;
+  L.image = args->fwd.out_color; L.opacity = args->fwd.out_opacity;
+  L.grad_out = args->one; L.grad_image = args->grad_image;
+  L.grad_a = args->grad_exposure; L.grad_b = args->grad_exposure + 1;
+  if ((rc = mgs_tracking_loss_forward(&L, stream)) != MGS_OK) return rc;
+  if ((rc = mgs_tracking_loss_backward(&L, stream)) != MGS_OK) return rc;
+  mgs_backward_args B;
+  memset(&B, 0, sizeof(B));
+  B.fwd = args->fwd;
+  B.grad_color = args->grad_image;
+  B.bwd = args->bwd;
+  B.grad_tau = args->grad_tau;
+  if ((rc = mgs_raster_backward(&B, stream)) != MGS_OK) return rc;
+  mgs_pose_adam_args A = args->adam;
+  A.grad_trans = args->grad_tau; A.grad_rot = args->grad_tau + 3;
+  A.grad_a = A.exposure_a ? args->grad_exposure : nullptr;
+  A.grad_b = A.exposure_b ? args->grad_exposure + 1 : nullptr;
+  return mgs_pose_adam_step(&A, stream);
 }
 
 int32_t mgs_profile_enable(int32_t on) {

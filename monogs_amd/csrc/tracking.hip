@@ -78,6 +78,17 @@ __global__ void k_pose_adam_update(mgs_pose_adam_args A) {
   }
 }
 
+// viewmatrix = T^T, projmatrix = viewmatrix @ projection (row-major 4x4, camera_utils.py:94-104)
+__global__ void k_camera_from_pose(const float* T, const float* proj, float* view, float* full) {
+  const int i = threadIdx.x >> 2, j = threadIdx.x & 3;      // 16 threads
+  if (threadIdx.x >= 16) return;
+  float acc = 0.f;
+  for (int k = 0; k < 4; k++) acc += T[4 * k + i] * proj[4 * k + j];   // view[i][k] = T[k][i]
+  const float v = T[4 * j + i];
+  full[4 * i + j] = acc;
+  view[4 * i + j] = v;
+}
+
 // ---------------------------------------------------------------------------------
 constexpr int kLossBlock = 256;
 constexpr int kLossBlocks = 512;
@@ -356,6 +367,14 @@ static int loss_blocks(int64_t hw) {
 using namespace mgs;
 
 extern "C" {
+
+int32_t mgs_camera_from_pose(const float* T, const float* projection, float* viewmatrix,
+                             float* projmatrix, void* stream) {
+  if (!T || !projection || !viewmatrix || !projmatrix) return MGS_ERR_BAD_ARGUMENT;
+  launch("camera_from_pose", k_camera_from_pose, dim3(1), dim3(64), (hipStream_t)stream, T, projection,
+         viewmatrix, projmatrix);
+  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+}
 
 int32_t mgs_pose_adam_step(const mgs_pose_adam_args* a, void* stream) {
   if (!a || !a->cam_rot_delta || !a->cam_trans_delta || !a->exp_avg || !a->exp_avg_sq || a->step < 1)

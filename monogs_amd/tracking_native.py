@@ -1,0 +1,167 @@
+"""First-order tracking iterations enqueued natively (one C-ABI call per iteration).
+
+`tracking_step_first_order[_fused]` in slam_loops.py mirror the reference's Python loop
+body (utils/slam_frontend.py:493-630) and spend ~1 ms of HOST time per iteration in
+autograd, tensor allocation and ctypes marshalling - more than the GPU needs for the whole
+iteration.  During tracking the map is frozen, so everything that does not change between
+iterations is prepared once here (activated Gaussian attributes, workspaces at a fixed pair
+capacity, the argument block) and an iteration is a single `mgs_tracking_iteration` call:
+camera matrices from T, rasteriser forward, monocular tracking objective, pose-only
+rasteriser backward, Adam + update_pose, all on the current stream with no host sync.
+
+Semantics per iteration are those of `tracking_step_first_order_fused`
+(tests/test_raster_gpu.py::test_native_tracking_matches_python_loop).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import _cabi
+from . import rasterizer as R
+
+
+class NativeTracker:
+    """Tracks `viewpoint` (slam_loops.ViewCamera-like: T, projection_matrix, FoVx/FoVy,
+    image size, original_image, rgb_pixel_mask_mapping, exposure_a/b/eps, cam_*_delta)
+    against the frozen `gaussians` (get_xyz/get_scaling/get_rotation/get_opacity/
+    get_features, active_sh_degree).  `viewpoint.T`, the exposure parameters and the
+    convergence flag live on the device and are updated in place by `step()`."""
+
+    def __init__(self, viewpoint, gaussians, background, huber_delta=0.01, lr_rot=0.003,
+                 lr_trans=0.001, lr_a=0.02, lr_b=0.02, betas=(0.9, 0.999), eps=1e-8,
+                 converged_threshold=1e-4, capacity_margin=1.5):
+        vp = viewpoint
+        dev = vp.T.device
+        if dev.type != "cuda":
+            raise RuntimeError("NativeTracker runs on the GPU only (HIP kernels, gfx950)")
+        self.vp, self.dev = vp, dev
+        f32 = lambda t: t.detach().to(dev, torch.float32).contiguous()
+        with torch.no_grad():
+            self.means = f32(gaussians.get_xyz)
+            sc = gaussians.get_scaling
+            self.scales = f32(sc.repeat(1, 3) if sc.shape[-1] == 1 else sc)
+            self.rots = f32(gaussians.get_rotation)
+            self.opac = f32(gaussians.get_opacity).reshape(-1)
+            self.shs = f32(gaussians.get_features)
+        N, K = int(self.means.shape[0]), int(self.shs.shape[1])
+        H, W = int(vp.image_height), int(vp.image_width)
+        self.N, self.H, self.W = N, H, W
+        assert vp.T.is_contiguous() and vp.T.dtype == torch.float32
+        self.proj = f32(vp.projection_matrix)
+        self.view = torch.empty(4, 4, device=dev)
+        self.full = torch.empty(4, 4, device=dev)
+        self.bg = f32(background).reshape(-1)
+        self.gt = f32(vp.original_image)
+        m = getattr(vp, "rgb_pixel_mask_mapping", None)
+        self.mask = None if m is None else f32(m)
+        lib = _cabi.lib()
+        stream = self._stream()
+        _cabi.check(lib.mgs_camera_from_pose(vp.T.data_ptr(), self.proj.data_ptr(), self.view.data_ptr(),
+                                             self.full.data_ptr(), stream), "mgs_camera_from_pose")
+
+        # one probing forward (stage 1 only) sizes the pair capacity for the whole run
+        shape = _cabi.RasterShape(N, W, H, int(gaussians.active_sh_degree), K, 0,
+                                  math.tan(0.5 * vp.FoVx), math.tan(0.5 * vp.FoVy), 1.0)
+        sizes = _cabi.workspace_sizes(shape)
+        self.geom = torch.empty(int(sizes.geom_bytes), dtype=torch.uint8, device=dev)
+        self.color = torch.empty(3, H, W, device=dev)
+        self.depth = torch.empty(1, H, W, device=dev)
+        self.opacity = torch.empty(1, H, W, device=dev)
+        self.radii = torch.empty(N, dtype=torch.int32, device=dev)
+        self.n_touched = torch.empty(N, dtype=torch.int32, device=dev)
+        a = _cabi.TrackingIterArgs()
+        f = a.fwd
+        f.shape = shape
+        f.means3D, f.scales, f.rotations = self.means.data_ptr(), self.scales.data_ptr(), self.rots.data_ptr()
+        f.opacities, f.shs = self.opac.data_ptr(), self.shs.data_ptr()
+        f.viewmatrix, f.projmatrix, f.projmatrix_raw = self.view.data_ptr(), self.full.data_ptr(), self.proj.data_ptr()
+        f.campos, f.bg, f.geom = self.view.data_ptr(), self.bg.data_ptr(), self.geom.data_ptr()
+        f.out_color, f.out_depth, f.out_opacity = self.color.data_ptr(), self.depth.data_ptr(), self.opacity.data_ptr()
+        f.radii, f.n_touched = self.radii.data_ptr(), self.n_touched.data_ptr()
+        _cabi.check(lib.mgs_raster_forward_project(C.byref(f), stream), "mgs_raster_forward_project")
+        off = int(sizes.off_counters)
+        self._counter = self.geom[off:off + 4].view(torch.int32)
+        D = int(self._counter.item())
+        self.capacity_margin = capacity_margin
+        self._alloc_bins(a, max(1024, int(D * capacity_margin)))
+
+        self.grad_image = torch.empty(3, H, W, device=dev)
+        self.grad_tau = torch.zeros(6, device=dev)
+        self.grad_exposure = torch.zeros(2, device=dev)
+        self.one = torch.ones(1, device=dev)
+        a.grad_image, a.grad_tau = self.grad_image.data_ptr(), self.grad_tau.data_ptr()
+        a.grad_exposure, a.one = self.grad_exposure.data_ptr(), self.one.data_ptr()
+        L = a.loss
+        self.partial = torch.empty(int(lib.mgs_tracking_loss_partial_count(H * W)), device=dev)
+        self.scalars = torch.zeros(2, device=dev)
+        L.gt = self.gt.data_ptr()
+        L.mask = None if self.mask is None else self.mask.data_ptr()
+        L.exposure_a, L.exposure_b = vp.exposure_a.data_ptr(), vp.exposure_b.data_ptr()
+        L.exposure_eps, L.huber_delta, L.num_pixels = float(vp.exposure_eps), float(huber_delta), H * W
+        L.partial, L.scalars = self.partial.data_ptr(), self.scalars.data_ptr()
+        A = a.adam
+        self.exp_avg = torch.zeros(8, device=dev)
+        self.exp_avg_sq = torch.zeros(8, device=dev)
+        self.converged = torch.zeros(1, dtype=torch.int32, device=dev)
+        A.cam_rot_delta, A.cam_trans_delta = vp.cam_rot_delta.data_ptr(), vp.cam_trans_delta.data_ptr()
+        A.exposure_a, A.exposure_b = vp.exposure_a.data_ptr(), vp.exposure_b.data_ptr()
+        A.exp_avg, A.exp_avg_sq = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
+        A.T, A.converged = vp.T.data_ptr(), self.converged.data_ptr()
+        (A.lr_rot, A.lr_trans, A.lr_a, A.lr_b, A.beta1, A.beta2, A.eps, A.converged_threshold) = (
+            lr_rot, lr_trans, lr_a, lr_b, betas[0], betas[1], eps, converged_threshold)
+        self.args = a
+        self.t = 0
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def _alloc_bins(self, a, cap):
+        a.fwd.shape.pair_capacity = cap
+        sizes = _cabi.workspace_sizes(a.fwd.shape)
+        self.bins = torch.empty(int(sizes.bins_bytes), dtype=torch.uint8, device=self.dev)
+        self.bwd = torch.empty(int(sizes.bwd_bytes), dtype=torch.uint8, device=self.dev)
+        a.fwd.bins, a.bwd = self.bins.data_ptr(), self.bwd.data_ptr()
+        self.capacity = cap
+
+    def step(self):
+        """Enqueue one iteration; returns the device convergence flag (int32[1])."""
+        self.t += 1
+        self.args.adam.step = self.t
+        _cabi.check(_cabi.lib().mgs_tracking_iteration(C.byref(self.args), self._stream()),
+                    "mgs_tracking_iteration")
+        return self.converged
+
+    @property
+    def loss(self):
+        return self.scalars[0]
+
+    def pairs(self) -> int:
+        """Pair count D of the last forward (host sync)."""
+        return int(self._counter.item())
+
+    def check_capacity(self):
+        """True if every iteration so far rendered completely; otherwise grows the workspaces
+        (the caller re-runs the affected iterations - the pose only moves by millimetres per
+        iteration, so a 1.5x margin is not reached in practice)."""
+        D = self.pairs()
+        if D <= self.capacity:
+            return True
+        self._alloc_bins(self.args, int(D * self.capacity_margin))
+        return False
+
+    def run(self, max_iters=100, check_every=10):
+        """The reference's loop (slam_frontend.py:493-630): iterate until converged or
+        max_iters; the flag is read back every `check_every` iterations."""
+        it = 0
+        while it < max_iters:
+            for _ in range(min(check_every, max_iters - it)):
+                self.step()
+                it += 1
+            if int(self.converged.item()):
+                break
+        if not self.check_capacity():
+            raise RuntimeError("pair capacity exceeded during tracking; re-run with the grown workspace")
+        return it
