@@ -523,7 +523,31 @@ __device__ __forceinline__ void mask_clear_bit(unsigned long long& m, int j) {
   asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(j));
 }
 
+#ifdef MGS_STAMP   // diagnostic build only (scratch/stamp.py): per-workgroup start/end stamps
+__device__ long long g_stamps[4 * 65536];
+extern "C" int mgs_debug_read_stamps(long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(long long) * n);
+}
+struct StampScope {
+  long long t0, c0;
+  __device__ StampScope() : t0(__builtin_amdgcn_s_memrealtime()), c0(__builtin_amdgcn_s_memtime()) {}
+  __device__ ~StampScope() {
+    if (threadIdx.x == 0 && blockIdx.x < 65536) {
+      g_stamps[4 * blockIdx.x + 0] = t0;
+      g_stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+      g_stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime() - c0;
+      g_stamps[4 * blockIdx.x + 3] = ((long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32) |
+                                     __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+    }
+  }
+};
+#define MGS_STAMP_SCOPE StampScope stamp_scope_
+#else
+#define MGS_STAMP_SCOPE
+#endif
+
 __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
+  MGS_STAMP_SCOPE;
   // per staged splat 48 B: (x, y, A', B') (C', opacity, r, g) (b, depth, -, -)
   __shared__ float4 s_rec[kSeg * 3];
   const int item = xcd_remap<kFwdChunk>(blockIdx.x);
