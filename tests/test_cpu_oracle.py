@@ -93,6 +93,91 @@ def test_losses_match_reference(gold):
 # SE(3): utils/pose_utils.py cannot be imported (lietorch absent) -> pin on matrix_exp
 # ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("mod", ["oracle", "product"])
+def _glsl_scene(seed=11, n=96):
+    """Gaussians in front of a moved camera with square pixels (the viewer's shader uses one
+    focal length for both axes), some far off-axis so the +-1.3 tan(fov) clamp is active."""
+    import math
+    from oracle import torch_raster as O
+    from monogs_amd import synthetic as S
+    g = torch.Generator().manual_seed(seed)
+    W, H, f = 160, 120, 140.0
+    tanx, tany = W / (2 * f), H / (2 * f)
+    T = O.se3_exp(torch.tensor([0.1, -0.05, 0.2, 0.05, -0.1, 0.03], dtype=torch.float64))
+    z = torch.rand(n, generator=g, dtype=torch.float64) * 4 + 0.5
+    u = (torch.rand(n, generator=g, dtype=torch.float64) * 3.4 - 1.7) * tanx    # beyond the clamp
+    v = (torch.rand(n, generator=g, dtype=torch.float64) * 3.4 - 1.7) * tany
+    p_cam = torch.stack([u * z, v * z, z], 1)
+    p_w = (p_cam - T[:3, 3]) @ T[:3, :3]                      # R^T (p_cam - t)
+    scales = torch.exp(torch.randn(n, 3, generator=g, dtype=torch.float64) * 0.5 - 3.0)
+    q = torch.nn.functional.normalize(torch.randn(n, 4, generator=g, dtype=torch.float64), dim=1)
+    V = T.t().contiguous()
+    proj = torch.zeros(4, 4, dtype=torch.float64)             # graphics_utils.py:56-77 shape
+    zn, zf = 0.01, 100.0
+    proj[0, 0], proj[1, 1] = 1 / tanx, 1 / tany
+    proj[2, 2], proj[2, 3], proj[3, 2] = zf / (zf - zn), -(zf * zn) / (zf - zn), 1.0
+    P = proj.t()
+    st = O.RasterSettings(H, W, tanx, tany, torch.zeros(3, dtype=torch.float64), 1.0, V, V @ P, P, 0, V,
+                          False, False)
+    return st, T, p_w, scales, q, f, tanx, tany
+
+
+def test_oracle_ewa_matches_the_reference_viewer_shader():
+    """Pins row a4 (projection + EWA) and its constants against the reference's own in-tree
+    restatement, gui/gl_render/shaders/gau_vert.glsl:60-154 (oracle/glsl_ewa.py follows it
+    line by line): 2-D covariance incl. the +-1.3 tan(fov) clamp and the +0.3 low-pass, and
+    the conic.  The viewer is y-up, so the off-diagonal term changes sign."""
+    from oracle import glsl_ewa as G
+    from oracle import torch_raster as O
+    st, T, p_w, scales, q, f, tanx, tany = _glsl_scene()
+    n = p_w.shape[0]
+    pr = O.project(p_w, None, None, torch.zeros(n, 3, dtype=torch.float64),
+                   torch.full((n,), 0.5, dtype=torch.float64), scales, q, None, st, None)
+    clamped = 0
+    for i in range(n):
+        cov2d, conic = G.splat(p_w[i].numpy(), scales[i].numpy(), q[i].numpy(), T.numpy(), f, tanx, tany)
+        want_cov = np.array([cov2d[0], -cov2d[1], cov2d[2]])
+        want_con = np.array([conic[0], -conic[1], conic[2]])
+        assert np.allclose(pr.cov2d[i].numpy(), want_cov, rtol=1e-9, atol=1e-12), i
+        assert np.allclose(pr.conic[i].numpy(), want_con, rtol=1e-8, atol=1e-12), i
+        pc = T.numpy() @ np.append(p_w[i].numpy(), 1.0)
+        clamped += abs(pc[0] / pc[2]) > 1.3 * tanx or abs(pc[1] / pc[2]) > 1.3 * tany
+    assert clamped >= 5           # the clamp branch was exercised
+
+
+def test_oracle_alpha_rule_matches_the_reference_viewer_shader():
+    """One Gaussian on a black background: the oracle's opacity image IS the per-pixel alpha;
+    inside the viewer's +-3 sigma quad it must equal gau_frag.glsl:20-26 (power > 0 and
+    alpha < 1/255 discarded, alpha capped at 0.99)."""
+    from oracle import glsl_ewa as G
+    from oracle import torch_raster as O
+    st, T, p_w, scales, q, f, tanx, tany = _glsl_scene(seed=5, n=24)
+    checked = capped = cut = 0
+    for i in range(24):
+        for op in (0.9999, 0.3, 0.02):
+            m, s_, q_ = p_w[i:i + 1], scales[i:i + 1] * 6.0, q[i:i + 1]
+            o = torch.tensor([[op]], dtype=torch.float64)
+            pr = O.project(m, None, None, torch.ones(1, 3, dtype=torch.float64), o.reshape(-1), s_, q_, None, st, None)
+            if int(pr.radii[0]) == 0:
+                continue
+            img, radii, dep, opa, nt, _ = O.rasterize(m, None, None, torch.ones(1, 3, dtype=torch.float64), o, s_, q_,
+                                                      None, st, None, None)
+            cov2d, conic = G.splat(m[0].numpy(), s_[0].numpy(), q_[0].numpy(), T.numpy(), f, tanx, tany)
+            hx, hy = G.quad_half_extent(cov2d)
+            cx, cy = pr.xy[0].numpy()
+            for py in range(st.image_height):
+                for px in range(st.image_width):
+                    dx, dy = px - cx, py - cy
+                    if abs(dx) > hx or abs(dy) > hy:
+                        continue
+                    want = G.fragment_alpha(conic, (dx, -dy), op)     # viewer is y-up
+                    got = float(opa[0, py, px])
+                    assert abs(got - want) <= 1e-9, (i, op, px, py, got, want)
+                    checked += 1
+                    capped += want == 0.99
+                    cut += want == 0.0
+    assert checked > 2000 and capped > 0 and cut > 0
+
+
 def test_se3_exp_is_the_matrix_exponential(mod):
     if mod == "oracle":
         from oracle.torch_raster import se3_exp as f

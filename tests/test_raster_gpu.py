@@ -6,6 +6,7 @@ Tolerances (BASELINE.json north_star): forward image L1 <= 1e-4; backward gradie
 handful of (pixel, splat) pairs may flip between two fp32 implementations).
 """
 import pytest
+import numpy as np
 import torch
 
 from conftest import gpu_settings, oracle_settings, rel_err
@@ -707,6 +708,58 @@ def test_native_tracking_matches_python_loop(built):
     assert n <= 200 and (vb.T.cpu() - torch.eye(4)).abs().max().item() < 0.5 * err0
     # pose-only backward through the plain C ABI: per-Gaussian gradients all NULL or all set
     assert trk.pairs() > 0
+
+
+def test_hip_splat_and_alpha_match_the_reference_viewer_shader(built):
+    """End-to-end pin of the HIP path against the reference's own in-tree restatement
+    (gau_vert.glsl:60-154 projection + EWA, gau_frag.glsl:20-26 alpha rule; followed line by
+    line in oracle/glsl_ewa.py): one Gaussian on a black background, so the rasteriser's
+    `opacity` output is the per-pixel alpha; inside the viewer's +-3 sigma quad it must equal
+    the fragment shader's value.  fp32 tolerance 1e-4 (the north-star's image tolerance);
+    pixels within 1e-3 relative of the 1/255 cut-off may fall on either side."""
+    from oracle import glsl_ewa as G
+    from monogs_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    from test_cpu_oracle import _glsl_scene
+    dev = _dev()
+    st64, T, p_w, scales, q, f, tanx, tany = _glsl_scene(seed=5, n=24)
+    st = GaussianRasterizationSettings(st64.image_height, st64.image_width, tanx, tany,
+                                       torch.zeros(3, device=dev), 1.0, st64.viewmatrix.float().to(dev),
+                                       st64.projmatrix.float().to(dev), st64.projmatrix_raw.float().to(dev),
+                                       0, st64.viewmatrix.float().to(dev), False, False)
+    ras = GaussianRasterizer(st)
+    checked = capped = cut = 0
+    for i in range(24):
+        for op in (0.9999, 0.3):
+            m, s_, q_ = p_w[i:i + 1], scales[i:i + 1] * 6.0, q[i:i + 1]
+            with torch.no_grad():
+                img, radii, dep, opa, nt = ras(
+                    means3D=m.float().to(dev), means2D=torch.zeros(1, 3, device=dev),
+                    colors_precomp=torch.ones(1, 3, device=dev),
+                    opacities=torch.tensor([[op]], device=dev), scales=s_.float().to(dev),
+                    rotations=q_.float().to(dev))
+            if int(radii[0]) == 0:
+                continue
+            opa = opa[0].cpu().numpy()
+            cov2d, conic = G.splat(m[0].numpy(), s_[0].numpy(), q_[0].numpy(), T.numpy(), f, tanx, tany)
+            hx, hy = G.quad_half_extent(cov2d)
+            pc = T.numpy() @ np.append(m[0].numpy(), 1.0)
+            cx = f * pc[0] / pc[2] + (st.image_width - 1) * 0.5
+            cy = f * pc[1] / pc[2] + (st.image_height - 1) * 0.5
+            for py in range(max(0, int(cy - hy)), min(st.image_height, int(cy + hy) + 2)):
+                for px in range(max(0, int(cx - hx)), min(st.image_width, int(cx + hx) + 2)):
+                    dx, dy = px - cx, py - cy
+                    if abs(dx) > hx or abs(dy) > hy:
+                        continue
+                    power = -0.5 * (conic[0] * dx * dx + conic[2] * dy * dy) + conic[1] * dx * dy
+                    raw = op * np.exp(power)
+                    if abs(raw * 255.0 - 1.0) < 1e-3 or abs(power) < 1e-6:
+                        continue
+                    want = G.fragment_alpha(conic, (dx, -dy), op)
+                    assert abs(float(opa[py, px]) - want) <= 1e-4, (i, op, px, py, float(opa[py, px]), want)
+                    checked += 1
+                    capped += want == 0.99
+                    cut += want == 0.0
+    assert checked > 1000 and capped > 0 and cut > 0
 
 
 def test_fused_lm_solve_matches_damped_lstsq(built):
