@@ -526,6 +526,9 @@ __global__ __launch_bounds__(kPreBlock) void k_preprocess_bwd(KP P, KB B) {
   }
 }
 
+// Fixed-order sum of the block partials -> grad_tau[6].  (Folding this into k_preprocess_bwd
+// with a last-workgroup ticket was measured slower: the hand-off makes every workgroup drain
+// its 20 MB of gradient stores before it may retire.)
 __global__ __launch_bounds__(384) void k_tau_reduce(KB B, int nblk) {
   // 6 components x 64 lanes; each lane strides the partials, then a wave sum.
   const int comp = threadIdx.x >> 6, lane = threadIdx.x & 63;

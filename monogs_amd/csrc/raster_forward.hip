@@ -187,44 +187,6 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_lds(KP P, int emit, int per
   }
 }
 
-// Exclusive prefix down the rows of bin_table, total -> tile_count.  64 tiles x 16 row
-// groups per workgroup; each thread owns kBinBlocks/8 rows in registers (independent
-// loads), the groups are stitched through LDS.
-constexpr int kColGroups = 16;
-constexpr int kColRows = kBinBlocks / kColGroups;
-
-__global__ __launch_bounds__(64 * kColGroups) void k_bin_colsum(KP P, int nblk) {
-  __shared__ int s_sum[kColGroups][64];
-  const int tl = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int t = blockIdx.x * 64 + tl;
-  int v[kColRows];
-  int sum = 0;
-#pragma unroll
-  for (int i = 0; i < kColRows; i++) {
-    const int b = grp * kColRows + i;
-    v[i] = (t < P.T && b < nblk) ? P.bin_table[(size_t)b * P.T + t] : 0;
-    sum += v[i];
-  }
-  s_sum[grp][tl] = sum;
-  __syncthreads();
-  int run = 0, tot = 0;
-#pragma unroll
-  for (int g = 0; g < kColGroups; g++) {
-    const int x = s_sum[g][tl];
-    if (g < grp) run += x;
-    tot += x;
-  }
-  if (t < P.T) {
-#pragma unroll
-    for (int i = 0; i < kColRows; i++) {
-      const int b = grp * kColRows + i;
-      if (b < nblk) P.bin_table[(size_t)b * P.T + t] = run;
-      run += v[i];
-    }
-    if (grp == 0) P.tile_count[t] = tot;
-  }
-}
-
 // Fallback for images with more tiles than fit an LDS table: global atomics.
 __global__ __launch_bounds__(256) void k_bin(KP P, int emit) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -325,8 +287,7 @@ __global__ __launch_bounds__(256) void k_scan_write(KP P) {
 // ---------------------------------------------------------------------------------
 // Exclusive scans of the T tile counts (-> tile_offset, D) and of the per-tile segment
 // counts ceil(n_t / kSeg) (-> seg_offset) by one 1024-thread workgroup.
-__global__ __launch_bounds__(1024) void k_tile_scan(KP P, int nbin) {
-  __shared__ int s_sum[1024], s_seg[1024];
+__device__ __forceinline__ void tile_scan_body(const KP& P, int nbin, int* s_sum, int* s_seg) {
   const int tid = threadIdx.x;
   if (nbin > 0) {   // exclusive scan of the binning blocks' pair totals (nbin <= 1024)
     const int v = tid < nbin ? P.scan_tmp[tid] : 0;
@@ -348,7 +309,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(KP P, int nbin) {
   const int lo = tid * per, hi = min(lo + per, P.T);
   int local = 0, lseg = 0;
   for (int i = lo; i < hi; i++) {
-    const int c = P.tile_count[i];
+    const int c = __hip_atomic_load(&P.tile_count[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     local += c;
     lseg += (c + kSeg - 1) / kSeg;
   }
@@ -365,7 +326,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(KP P, int nbin) {
   }
   int run = s_sum[tid] - local, rseg = s_seg[tid] - lseg;
   for (int i = lo; i < hi; i++) {
-    const int c = P.tile_count[i];
+    const int c = __hip_atomic_load(&P.tile_count[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     P.tile_offset[i] = run;
     P.seg_offset[i] = rseg;
     run += c;
@@ -378,6 +339,68 @@ __global__ __launch_bounds__(1024) void k_tile_scan(KP P, int nbin) {
     P.counters[1] = s_seg[1023];
   }
 }
+
+__global__ __launch_bounds__(1024) void k_tile_scan(KP P, int nbin) {
+  __shared__ int s_sum[1024], s_seg[1024];
+  tile_scan_body(P, nbin, s_sum, s_seg);
+}
+
+// ---------------------------------------------------------------------------------
+// Exclusive prefix down the rows of bin_table, total -> tile_count.  64 tiles x 16 row
+// groups per workgroup; each thread owns kBinBlocks/8 rows in registers (independent
+// loads), the groups are stitched through LDS.
+constexpr int kColGroups = 16;
+constexpr int kColRows = kBinBlocks / kColGroups;
+
+__global__ __launch_bounds__(64 * kColGroups) void k_bin_colsum(KP P, int nblk) {
+  __shared__ int s_sum2[2048];
+  int (*s_sum)[64] = reinterpret_cast<int (*)[64]>(s_sum2);
+  const int tl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + tl;
+  int v[kColRows];
+  int sum = 0;
+#pragma unroll
+  for (int i = 0; i < kColRows; i++) {
+    const int b = grp * kColRows + i;
+    v[i] = (t < P.T && b < nblk) ? P.bin_table[(size_t)b * P.T + t] : 0;
+    sum += v[i];
+  }
+  s_sum[grp][tl] = sum;
+  __syncthreads();
+  int run = 0, tot = 0;
+#pragma unroll
+  for (int g = 0; g < kColGroups; g++) {
+    const int x = s_sum[g][tl];
+    if (g < grp) run += x;
+    tot += x;
+  }
+  if (t < P.T) {
+#pragma unroll
+    for (int i = 0; i < kColRows; i++) {
+      const int b = grp * kColRows + i;
+      if (b < nblk) P.bin_table[(size_t)b * P.T + t] = run;
+      run += v[i];
+    }
+    if (grp == 0) __hip_atomic_store(&P.tile_count[t], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // The workgroup that finishes last also runs the tile scan (saves a dependent launch).
+  // Fence-free hand-off (MI355X_MICROARCH.md, "Hand-offs measured with sc1 loads"): the tile
+  // totals are stored write-through (sc1) by wave 0 (see above), that wave drains them and one
+  // of its lanes takes an agent-scope ticket; the last arriver reads tile_count with sc1 loads
+  // behind a workgroup barrier.  counters[3] was zeroed by k_preprocess of this forward.
+  __shared__ int s_last;
+  if (threadIdx.x < 64) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) {
+      const int ticket = atomicAdd(&P.counters[3], 1);
+      s_last = ticket == (int)gridDim.x - 1;
+    }
+  }
+  __syncthreads();
+  if (!s_last) return;
+  tile_scan_body(P, nblk, s_sum2, s_sum2 + 1024);
+}
+
 
 // ---------------------------------------------------------------------------------
 // Bitonic network for arbitrary n with virtual +inf padding: every comparator puts the
@@ -676,8 +699,24 @@ static inline int check_launch() {
   return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
+static inline int num_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, v = 0;
+    cus = (hipGetDevice(&dev) == hipSuccess &&
+           hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  return cus;
+}
+
+// A 1024-thread binning workgroup fills a CU (its SGPR count admits one per CU), so a grid
+// just above the CU count runs a second, nearly empty round: round down to a whole number of
+// rounds (300k Gaussians: 293 -> 256 workgroups of 1172).
 static inline int bin_blocks(int N) {
-  return max(1, min(kBinBlocks, (N + kBinThreads - 1) / kBinThreads));
+  int b = max(1, min(kBinBlocks, (N + kBinThreads - 1) / kBinThreads));
+  const int cus = num_cus();
+  if (b > cus) b = b / cus * cus;
+  return b;
 }
 
 int launch_forward_project(const KP& P, hipStream_t st) {
@@ -686,8 +725,7 @@ int launch_forward_project(const KP& P, hipStream_t st) {
   if (P.T <= kBinMaxTilesLds) {
     const int nblk = bin_blocks(P.N), per = (P.N + nblk - 1) / nblk;
     launch_smem("bin_count", k_bin_lds, dim3(nblk), dim3(kBinThreads), sizeof(int) * (size_t)P.T, st, P, 0, per);
-    launch("bin_colsum", k_bin_colsum, dim3((P.T + 63) / 64), dim3(64 * kColGroups), st, P, nblk);
-    launch("tile_scan", k_tile_scan, dim3(1), dim3(1024), st, P, nblk);
+    launch("bin_colsum", k_bin_colsum, dim3((P.T + 63) / 64), dim3(64 * kColGroups), st, P, nblk);   // + tile scan
   } else {
     launch("bin_count", k_bin, dim3((P.N + 255) / 256), dim3(256), st, P, 0);
     const int nscan = (P.N + kScanBlock - 1) / kScanBlock;

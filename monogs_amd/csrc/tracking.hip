@@ -403,7 +403,8 @@ int32_t mgs_mapping_loss_backward(const mgs_mapping_loss_args* a, void* stream) 
   if (!map_args_ok(a) || !a->grad_out || !a->grad_image) return MGS_ERR_BAD_ARGUMENT;
   const int nb = loss_blocks(a->num_pixels);
   launch("map_loss_bwd", k_map_loss_bwd, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a);
-  launch("map_loss_bwd_fin", k_map_loss_bwd_finish, dim3(1), dim3(kLossBlock), (hipStream_t)stream, *a, nb);
+  if (a->grad_a || a->grad_b)   // exposure gradients are the only consumers of the partial sums
+    launch("map_loss_bwd_fin", k_map_loss_bwd_finish, dim3(1), dim3(kLossBlock), (hipStream_t)stream, *a, nb);
   return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
