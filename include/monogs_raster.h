@@ -287,6 +287,99 @@ typedef struct mgs_tracking_iter_args {
 
 int32_t mgs_tracking_iteration(const mgs_tracking_iter_args* args, void* stream);
 
+
+/* ---- map maintenance on the device ---------------------------------- */
+
+#define MGS_ADAM_MAX_GROUPS 8
+#define MGS_GATHER_MAX_TENSORS 24
+
+/* torch.optim.Adam step (betas / eps / bias correction as PyTorch, no weight decay, no
+ * amsgrad) over all parameter groups of GaussianModel.training_setup
+ * (gaussian_splatting/scene/gaussian_model.py:252-285; stepped at utils/slam_backend.py:142,
+ * 322,365) in one launch. */
+typedef struct mgs_adam_group {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int64_t numel;
+  float lr;
+  int32_t step;          /* 1-based step count of THIS tensor (PyTorch keeps it per parameter:
+                            a tensor without a gradient does not advance) */
+} mgs_adam_group;
+
+/* betas / eps are doubles so that 1 - beta rounds to fp32 exactly as in PyTorch (which
+ * evaluates it in Python floats): with a float beta2 = 0.999f, 1 - beta2 is off by 1.3e-5. */
+int32_t mgs_adam_step_multi(const mgs_adam_group* groups, int32_t num_groups, double beta1,
+                            double beta2, double eps, void* stream);
+
+/* Rebuild plan of GaussianModel.densify_and_prune (gaussian_model.py:674-691 =
+ * densify_and_clone :636-672, densify_and_split :598-634, prune_points :540-556) or, with
+ * prune_mask != NULL, of prune_points(mask) alone.  Rows of the rebuilt arrays, in the
+ * reference's order: surviving originals, surviving clones, first split children, second split
+ * children (each group in index order - stable).
+ *   mgs_map_plan_count: per-Gaussian decisions -> flags, totals[0..3] = surviving originals,
+ *                       clones, split parents (so rows = t0 + t1 + 2 * t2) and t3 = ALL Gaussians
+ *                       selected for splitting (the reference draws 2 * t3 random offsets at :608-609
+ *                       before the final prune removes some children);
+ *   mgs_map_plan_emit:  src_index[row] = parent | kind << 30 (kind 0 original, 1 clone,
+ *                       2 / 3 first / second child), rows entries; noise_row[k] = row of the
+ *                       [2 * t3, 3] noise tensor used by the k-th child row, 2 * t2 entries.
+ * The caller reads totals between the two calls to allocate (one host sync per rebuild). */
+typedef struct mgs_map_plan_args {
+  int32_t n;
+  /* densify_and_prune inputs (ignored when prune_mask is given) */
+  const float* grad_accum;      /* [n] xyz_gradient_accum */
+  const float* denom;           /* [n] */
+  const float* log_scales;      /* [n,3] _scaling */
+  const float* opacity_logit;   /* [n]   _opacity */
+  float grad_threshold;         /* max_grad */
+  float dense_extent;           /* percent_dense * extent */
+  float min_opacity;
+  float big_extent;             /* 0.1 * extent when max_screen_size is set, else <= 0 */
+  const uint8_t* prune_mask;    /* [n] 1 = remove, or NULL */
+  /* scratch / outputs */
+  uint8_t* flags;               /* [n] */
+  int32_t* block_counts;        /* [4 * mgs_map_plan_blocks(n)] */
+  int32_t* totals;              /* [4] */
+  uint32_t* src_index;          /* [rows], mgs_map_plan_emit only */
+  int32_t* noise_row;           /* [max(1, 2 * totals[2])], mgs_map_plan_emit only */
+} mgs_map_plan_args;
+
+int32_t mgs_map_plan_blocks(int32_t n);
+int32_t mgs_map_plan_count(const mgs_map_plan_args* args, void* stream);
+int32_t mgs_map_plan_emit(const mgs_map_plan_args* args, void* stream);
+
+/* Rebuild per-Gaussian tensors (32-bit elements, `width` per row) from a plan in one launch:
+ * dst[row, :] = f(src[parent(row), :]). */
+enum {
+  MGS_GATHER_COPY = 0,           /* every row copies its parent (features, opacity, rotation, ids) */
+  MGS_GATHER_ZERO_NEW = 1,       /* originals copy, clones / children get 0 (Adam moments, :560-577) */
+  MGS_GATHER_SPLIT_SCALING = 2,  /* children: log(exp(s) / 1.6)  (:615-617), float */
+  MGS_GATHER_SPLIT_XYZ = 3       /* children: xyz + R(q) (noise * exp(s))  (:609-614), float, width 3 */
+};
+
+typedef struct mgs_gather_tensor {
+  const void* src;
+  void* dst;
+  int32_t width;
+  int32_t mode;
+} mgs_gather_tensor;
+
+typedef struct mgs_map_gather_args {
+  mgs_gather_tensor tensors[MGS_GATHER_MAX_TENSORS];
+  int32_t num_tensors;
+  int64_t rows;                 /* rows of the rebuilt arrays */
+  int32_t num_children;         /* totals[2]; the last 2 * num_children rows are split children */
+  const uint32_t* src_index;
+  const float* rotations;       /* parents' _rotation [n,4]   (MGS_GATHER_SPLIT_XYZ) */
+  const float* log_scales;      /* parents' _scaling [n,3]    (MGS_GATHER_SPLIT_XYZ) */
+  const float* noise;           /* [2 * totals[3], 3] unit normals */
+  const int32_t* noise_row;     /* from mgs_map_plan_emit */
+} mgs_map_gather_args;
+
+int32_t mgs_map_gather(const mgs_map_gather_args* args, void* stream);
+
 /* Per-kernel timing (diagnostics; used by bench.py for the roofline line).  While
  * enabled every kernel launch is bracketed by hipEvents on the launch stream.
  * mgs_profile_read waits for the recorded events, aggregates them by kernel name into

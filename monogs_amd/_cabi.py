@@ -21,6 +21,8 @@ EXPORTS = (
     "mgs_pose_adam_step", "mgs_tracking_loss_partial_count", "mgs_tracking_loss_forward",
     "mgs_tracking_loss_backward", "mgs_lm_solve_step", "mgs_mapping_loss_forward",
     "mgs_mapping_loss_backward", "mgs_camera_from_pose", "mgs_tracking_iteration",
+    "mgs_adam_step_multi", "mgs_map_plan_blocks", "mgs_map_plan_count", "mgs_map_plan_emit",
+    "mgs_map_gather",
 )
 
 _fp = C.c_void_p  # device pointers travel as plain addresses
@@ -89,6 +91,32 @@ class TrackingIterArgs(C.Structure):
                 ("adam", PoseAdamArgs)]
 
 
+ADAM_MAX_GROUPS = 8
+GATHER_MAX_TENSORS = 24
+GATHER_COPY, GATHER_ZERO_NEW, GATHER_SPLIT_SCALING, GATHER_SPLIT_XYZ = 0, 1, 2, 3
+
+
+class AdamGroup(C.Structure):
+    _fields_ = [("param", _fp), ("grad", _fp), ("exp_avg", _fp), ("exp_avg_sq", _fp),
+                ("numel", C.c_int64), ("lr", C.c_float), ("step", C.c_int32)]
+
+
+class MapPlanArgs(C.Structure):
+    _fields_ = ([("n", C.c_int32)] + [(n, _fp) for n in ("grad_accum", "denom", "log_scales", "opacity_logit")]
+                + [(n, C.c_float) for n in ("grad_threshold", "dense_extent", "min_opacity", "big_extent")]
+                + [(n, _fp) for n in ("prune_mask", "flags", "block_counts", "totals", "src_index", "noise_row")])
+
+
+class GatherTensor(C.Structure):
+    _fields_ = [("src", _fp), ("dst", _fp), ("width", C.c_int32), ("mode", C.c_int32)]
+
+
+class MapGatherArgs(C.Structure):
+    _fields_ = [("tensors", GatherTensor * GATHER_MAX_TENSORS), ("num_tensors", C.c_int32),
+                ("rows", C.c_int64), ("num_children", C.c_int32), ("src_index", _fp),
+                ("rotations", _fp), ("log_scales", _fp), ("noise", _fp), ("noise_row", _fp)]
+
+
 _lib = None
 
 
@@ -113,6 +141,16 @@ def lib():
     L.mgs_camera_from_pose.argtypes = [C.c_void_p] * 5
     L.mgs_tracking_iteration.restype = C.c_int32
     L.mgs_tracking_iteration.argtypes = [C.POINTER(TrackingIterArgs), C.c_void_p]
+    L.mgs_adam_step_multi.restype = C.c_int32
+    L.mgs_adam_step_multi.argtypes = [C.POINTER(AdamGroup), C.c_int32, C.c_double, C.c_double, C.c_double,
+                                      C.c_void_p]
+    L.mgs_map_plan_blocks.restype = C.c_int32
+    L.mgs_map_plan_blocks.argtypes = [C.c_int32]
+    for fn in (L.mgs_map_plan_count, L.mgs_map_plan_emit):
+        fn.restype = C.c_int32
+        fn.argtypes = [C.POINTER(MapPlanArgs), C.c_void_p]
+    L.mgs_map_gather.restype = C.c_int32
+    L.mgs_map_gather.argtypes = [C.POINTER(MapGatherArgs), C.c_void_p]
     L.mgs_abi_version.restype = C.c_int32
     L.mgs_status_string.restype = C.c_char_p
     L.mgs_status_string.argtypes = [C.c_int32]

@@ -92,7 +92,6 @@ def test_losses_match_reference(gold):
 # ---------------------------------------------------------------------------------------
 # SE(3): utils/pose_utils.py cannot be imported (lietorch absent) -> pin on matrix_exp
 # ---------------------------------------------------------------------------------------
-@pytest.mark.parametrize("mod", ["oracle", "product"])
 def _glsl_scene(seed=11, n=96):
     """Gaussians in front of a moved camera with square pixels (the viewer's shader uses one
     focal length for both axes), some far off-axis so the +-1.3 tan(fov) clamp is active."""
@@ -178,6 +177,7 @@ def test_oracle_alpha_rule_matches_the_reference_viewer_shader():
     assert checked > 2000 and capped > 0 and cut > 0
 
 
+@pytest.mark.parametrize("mod", ["oracle", "product"])
 def test_se3_exp_is_the_matrix_exponential(mod):
     if mod == "oracle":
         from oracle.torch_raster import se3_exp as f

@@ -916,3 +916,129 @@ def test_keyframe_insertion_on_device(built):
     assert (rots[:, 0] == 1).all() and (rots[:, 1:] == 0).all() and torch.allclose(torch.sigmoid(opac), torch.full_like(opac, 0.5))
     d = monocular_depth_prior(H, W, 2.0, dev, g)
     assert abs(d.mean().item() - 2.0 * (1 - 0.025)) < 0.01
+
+
+# ---------------------------------------------------------------------------------------
+# map maintenance on the device
+# ---------------------------------------------------------------------------------------
+class _Model:
+    """GaussianModel-shaped holder (gaussian_model.py:30-52, :247-285)."""
+    percent_dense = 0.01
+
+
+def _make_model(n, dev, seed, fused, rest=0):
+    from monogs_amd.map_update import FusedGaussianAdam
+    g = torch.Generator().manual_seed(seed)
+    cpu = {
+        "xyz": torch.randn(n, 3, generator=g),
+        "f_dc": torch.randn(n, 1, 3, generator=g),
+        "f_rest": torch.randn(n, rest, 3, generator=g),
+        "opacity": torch.randn(n, 1, generator=g) * 2.0,
+        "scaling": torch.randn(n, 3, generator=g) * 0.7 - 3.0,
+        "rotation": torch.randn(n, 4, generator=g),
+    }
+    m = _Model()
+    import torch.nn as nn
+    attr = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity",
+            "scaling": "_scaling", "rotation": "_rotation"}
+    groups = []
+    lrs = {"xyz": 1.6e-4, "f_dc": 2.5e-3, "f_rest": 1.25e-4, "opacity": 0.05, "scaling": 1e-3, "rotation": 1e-3}
+    for name, t in cpu.items():
+        p = nn.Parameter(t.clone().to(dev))
+        setattr(m, attr[name], p)
+        groups.append({"params": [p], "lr": lrs[name], "name": name})
+    m.optimizer = FusedGaussianAdam(groups, lr=0.0, eps=1e-15) if fused else torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+    m.xyz_gradient_accum = (torch.rand(n, 1, generator=g) * 4e-4).to(dev)
+    m.denom = torch.randint(0, 3, (n, 1), generator=g).float().to(dev)      # zeros -> NaN grads
+    m.max_radii2D = torch.rand(n, generator=g).to(dev) * 30
+    m.unique_kfIDs = torch.randint(0, 9, (n,), generator=g).int().to(dev)
+    m.n_obs = torch.randint(0, 5, (n,), generator=g).int().to(dev)
+    return m, cpu, attr
+
+
+def test_fused_gaussian_adam_matches_torch_adam(built):
+    dev = _dev()
+    ma, cpu, attr = _make_model(3001, dev, 7, fused=True, rest=3)
+    mb, _, _ = _make_model(3001, dev, 7, fused=False, rest=3)
+    g = torch.Generator().manual_seed(1)
+    for it in range(6):
+        for name, a in attr.items():
+            grad = torch.randn(getattr(ma, a).shape, generator=g) * (10.0 ** -(it % 3))
+            getattr(ma, a).grad = grad.clone().to(dev)
+            getattr(mb, a).grad = grad.clone().to(dev)
+        if it == 3:      # update_learning_rate (gaussian_model.py:287-300) edits the group in place
+            for opt in (ma.optimizer, mb.optimizer):
+                opt.param_groups[0]["lr"] = 3.3e-5
+        if it == 4:      # a group without a gradient is skipped
+            ma._features_rest.grad = None
+            mb._features_rest.grad = None
+        ma.optimizer.step()
+        mb.optimizer.step()
+    for name, a in attr.items():
+        pa, pb = getattr(ma, a), getattr(mb, a)
+        assert torch.allclose(pa, pb, rtol=2e-6, atol=1e-7), name
+        sa, sb = ma.optimizer.state[pa], mb.optimizer.state[pb]
+        assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=1e-5, atol=1e-7), name   # lerp rounding
+        assert torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=1e-5, atol=1e-10), name
+
+
+def _state_of(m, attr, cpu_names):
+    st = {}
+    for name, a in attr.items():
+        p = getattr(m, a)
+        st[name] = p.detach().cpu().clone()
+        s = m.optimizer.state.get(p)
+        st["exp_avg_" + name] = s["exp_avg"].cpu().clone()
+        st["exp_avg_sq_" + name] = s["exp_avg_sq"].cpu().clone()
+    st["kf"], st["n_obs"] = m.unique_kfIDs.cpu().clone(), m.n_obs.cpu().clone()
+    st["grad_accum"], st["denom"] = m.xyz_gradient_accum.cpu().clone(), m.denom.cpu().clone()
+    st["max_radii"] = m.max_radii2D.cpu().clone()
+    return st
+
+
+@pytest.mark.parametrize("fused,max_screen_size,rest", [(True, 20, 0), (False, None, 3)])
+def test_densify_and_prune_matches_the_reference_restatement(built, fused, max_screen_size, rest):
+    """monogs_amd.map_update.densify_and_prune (plan + one gather launch) against the PyTorch
+    restatement of gaussian_model.py:598-691: same rows in the same order, parameters, Adam
+    moments, keyframe ids, observation counts and zeroed statistics."""
+    from monogs_amd import map_update as MU
+    from oracle import map_update_ref as REF
+    dev = _dev()
+    n = 5000
+    m, cpu, attr = _make_model(n, dev, 11, fused=fused, rest=rest)
+    g = torch.Generator().manual_seed(2)
+    for a in attr.values():      # two optimiser steps so that the Adam moments are populated
+        getattr(m, a).grad = torch.randn(getattr(m, a).shape, generator=g).to(dev) * 1e-2
+    m.optimizer.step()
+    m.optimizer.step()
+    before = _state_of(m, attr, cpu)
+    extent, max_grad, min_opacity = 6.0, 2e-4, 0.1
+    scale = torch.exp(before["scaling"])
+    grads = before["grad_accum"] / before["denom"]
+    grads[grads.isnan()] = 0
+    n_split = int(((grads.squeeze(-1) >= max_grad) & (scale.max(1).values > m.percent_dense * extent)).sum())
+    assert n_split > 20
+    noise = torch.randn(2 * n_split, 3, generator=g)
+    want = REF.densify_and_prune({k: v.clone() for k, v in before.items()}, max_grad, min_opacity, extent,
+                                 max_screen_size, m.percent_dense, noise)
+    MU.densify_and_prune(m, max_grad, min_opacity, extent, max_screen_size, noise=noise.to(dev))
+    got = _state_of(m, attr, cpu)
+    assert got["xyz"].shape[0] == want["xyz"].shape[0] and got["xyz"].shape[0] != n
+    for k, w in want.items():
+        gk = got[k]
+        assert gk.shape == w.shape, (k, gk.shape, w.shape)
+        if w.dtype.is_floating_point:
+            assert torch.allclose(gk, w, rtol=1e-5, atol=1e-6), k
+        else:
+            assert torch.equal(gk, w.to(gk.dtype)), k
+    # the rebuilt parameters are leaves registered in the optimiser
+    for grp in m.optimizer.param_groups:
+        assert grp["params"][0] is getattr(m, attr[grp["name"]]) and grp["params"][0].requires_grad
+
+    # prune_points(mask) alone (slam_backend.py:86,280)
+    mask = torch.rand(got["xyz"].shape[0], generator=g) < 0.3
+    want2 = REF.prune_points(got, mask)
+    MU.prune_points(m, mask.to(dev))
+    got2 = _state_of(m, attr, cpu)
+    for k, w in want2.items():
+        assert got2[k].shape == w.shape and torch.equal(got2[k], w.to(got2[k].dtype)), k
