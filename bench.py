@@ -109,6 +109,60 @@ def bench_tracking(sc, dev, iters):
     return out
 
 
+def bench_map_update(sc, dev):
+    """Map maintenance on the SYN-C map: the Gaussian optimiser step
+    (fused HIP launch vs torch.optim.Adam, gaussian_model.py:285) and one densify_and_prune
+    (gaussian_model.py:674-691) through the plan + gather kernels."""
+    import torch.nn as nn
+    from monogs_amd.map_update import FusedGaussianAdam, densify_and_prune
+    N = sc.means3D.shape[0]
+    names = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+    attr = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+    src = (sc.means3D, sc.features_dc, sc.features_dc.new_zeros(N, 0, 3), sc.opacity_logit.reshape(N, 1),
+           sc.log_scales, sc.rot)
+    out = {}
+    for kind in ("torch", "fused"):
+        class M:
+            percent_dense = 0.01
+        m = M()
+        groups = []
+        for n_, a, t in zip(names, attr, src):
+            p = nn.Parameter(t.clone().float().to(dev).contiguous())
+            setattr(m, a, p)
+            groups.append({"params": [p], "lr": 1e-3, "name": n_})
+        opt = (torch.optim.Adam(groups, lr=0.0, eps=1e-15) if kind == "torch"
+               else FusedGaussianAdam(groups, lr=0.0, eps=1e-15))
+        m.optimizer = opt
+        grads = [torch.randn_like(g["params"][0]) * 1e-3 for g in groups]
+
+        def step():
+            for g, gr in zip(groups, grads):
+                g["params"][0].grad = gr
+            opt.step()
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            step()
+        torch.cuda.synchronize()
+        out[f"adam_{kind}_us"] = round((time.perf_counter() - t0) / 50 * 1e6, 1)
+    # densify_and_prune on the fused-optimiser model (statistics chosen so ~10 % clone/split)
+    g = torch.Generator(device=dev).manual_seed(0)
+    m.xyz_gradient_accum = torch.rand(N, 1, device=dev, generator=g) * 2.2e-4
+    m.denom = torch.ones(N, 1, device=dev)
+    m.max_radii2D = torch.zeros(N, device=dev)
+    m.unique_kfIDs = torch.zeros(N, dtype=torch.int32, device=dev)
+    m.n_obs = torch.zeros(N, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    densify_and_prune(m, 2e-4, 0.005, 6.0, 20)
+    torch.cuda.synchronize()
+    out["densify_and_prune_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+    out["gaussians_before_after"] = [N, int(m._xyz.shape[0])]
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -254,6 +308,10 @@ def main():
     if rank == 0 and not distributed and not args.no_tracking:
         tracking = bench_tracking(sc, dev, args.tracking_iters)
 
+    map_update = None
+    if rank == 0 and not distributed and not args.no_tracking:
+        map_update = bench_map_update(sc, dev)
+
     if rank == 0:
         out = {
             "metric": "rasteriser fwd+bwd fps @640x480/300k Gaussians",
@@ -266,7 +324,7 @@ def main():
                        "pairs_D": D, "views_per_step": world,
                        "parallelism": f"keyframe-parallel x{world}" if distributed else "single view"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels_us": kernels,
-            "tracking": tracking,
+            "tracking": tracking, "map_update": map_update,
         }
         print(json.dumps(out))
     if distributed:
