@@ -1,0 +1,130 @@
+"""CPU tests of the offline evaluation helpers."""
+import os
+
+import numpy as np
+import torch
+
+from monogs_amd import eval_metrics as E
+
+
+def _rand_rot(g):
+    q = torch.randn(4, generator=g).double().numpy()
+    return E._quat_xyzw_to_matrix(q)
+
+
+def test_umeyama_recovers_a_similarity_and_ate_is_zero():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 40, generator=g).double().numpy()
+    R0, t0, c0 = _rand_rot(g), np.array([0.3, -1.2, 2.0]), 1.7
+    y = c0 * R0 @ x + t0[:, None]
+    R, t, c = E.umeyama_alignment(x, y, with_scale=True)
+    assert np.allclose(R, R0, atol=1e-10) and np.allclose(t, t0, atol=1e-10) and abs(c - c0) < 1e-10
+    # rigid-only alignment of a scaled copy leaves a residual; of an unscaled copy none
+    R, t, c = E.umeyama_alignment(x, R0 @ x + t0[:, None], with_scale=False)
+    assert c == 1.0 and np.allclose(R, R0, atol=1e-10)
+
+    def poses(pts):
+        out = []
+        for k in range(pts.shape[1]):
+            T = np.eye(4)
+            T[:3, 3] = pts[:, k]
+            out.append(T)
+        return out
+    s = E.ate_statistics(poses(y), poses(x), monocular=True)
+    assert s["rmse"] < 1e-9
+    s = E.ate_statistics(poses(y), poses(x), monocular=False)     # scale 1.7 not corrected
+    assert s["rmse"] > 0.1
+    noisy = y + 0.01 * torch.randn(3, 40, generator=g).double().numpy()
+    s = E.ate_statistics(poses(noisy), poses(x), monocular=True)
+    assert 0.005 < s["rmse"] < 0.03 and s["min"] <= s["median"] <= s["max"]
+
+
+def test_reflection_case_returns_a_proper_rotation():
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 12, generator=g).double().numpy()
+    x[2] *= 1e-3                                   # nearly planar: the SVD sign is ambiguous
+    y = np.diag([1.0, 1.0, -1.0]) @ x
+    R, t, c = E.umeyama_alignment(x, y, with_scale=False)
+    assert abs(np.linalg.det(R) - 1.0) < 1e-9
+
+
+def test_psnr_matches_the_reference_helper_and_ssim_properties():
+    g = torch.Generator().manual_seed(1)
+    a = torch.rand(2, 3, 24, 32, generator=g)
+    b = (a + 0.05 * torch.randn(2, 3, 24, 32, generator=g)).clamp(0, 1)
+    want = 20 * torch.log10(1.0 / torch.sqrt(((a - b) ** 2).reshape(2, -1).mean(1, keepdim=True)))
+    assert torch.allclose(E.psnr(a, b), want)
+    ref = "/root/reference"
+    if os.path.isdir(ref):      # the reference's own PSNR imports cleanly
+        import importlib.util
+        spec = importlib.util.spec_from_file_location(
+            "ref_image_utils", os.path.join(ref, "gaussian_splatting/utils/image_utils.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        assert torch.allclose(E.psnr(a, b), mod.psnr(a, b))
+    assert abs(E.ssim(a, a).item() - 1.0) < 1e-6
+    s_ab = E.ssim(a, b).item()
+    assert 0.3 < s_ab < 1.0 and abs(s_ab - E.ssim(b, a).item()) < 1e-6
+    assert E.ssim(a, b, size_average=False).shape == (2,)
+    # direct evaluation of the definition at one interior pixel
+    img1, img2 = a[:1, :1], b[:1, :1]
+    w = E._gauss_window(11, 1.5, 1, img1)[0, 0]
+    p1, p2 = img1[0, 0, 5:16, 8:19], img2[0, 0, 5:16, 8:19]
+    mu1, mu2 = (w * p1).sum(), (w * p2).sum()
+    s11, s22, s12 = (w * p1 * p1).sum() - mu1 ** 2, (w * p2 * p2).sum() - mu2 ** 2, (w * p1 * p2).sum() - mu1 * mu2
+    want = ((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 ** 2 + mu2 ** 2 + 1e-4) * (s11 + s22 + 9e-4))
+    from torch.nn import functional as F
+    full = E.ssim(img1, img2, size_average=False)
+    mu_map = F.conv2d(img1, E._gauss_window(11, 1.5, 1, img1), padding=5)
+    assert torch.allclose(mu_map[0, 0, 10, 13], mu1, atol=1e-6)
+    assert full.shape == (1,) and torch.isfinite(want)
+
+
+def test_tum_sequence_reader(tmp_path):
+    from PIL import Image
+    d = tmp_path / "seq"
+    (d / "rgb").mkdir(parents=True)
+    (d / "depth").mkdir()
+    rgb_lines, dep_lines, gt_lines = ["# color images"], ["# depth maps"], ["# ground truth trajectory"]
+    for i in range(6):
+        t = 100.0 + i * 0.02              # 50 Hz: the 32 fps sub-sampling drops every other frame
+        Image.fromarray(np.full((4, 6, 3), 40 * i, np.uint8)).save(d / "rgb" / f"{i}.png")
+        Image.fromarray(np.full((4, 6), 5000 * (i + 1), np.uint16)).save(d / "depth" / f"{i}.png")
+        rgb_lines.append(f"{t:.4f} rgb/{i}.png")
+        dep_lines.append(f"{t + 0.003:.4f} depth/{i}.png")
+        gt_lines.append(f"{t + 0.001:.4f} {i * 0.1} 0 0 0 0 0 1")
+    rgb_lines.append("200.0 rgb/0.png")     # no depth / pose within 0.08 s: dropped
+    (d / "rgb.txt").write_text("\n".join(rgb_lines))
+    (d / "depth.txt").write_text("\n".join(dep_lines))
+    (d / "groundtruth.txt").write_text("\n".join(gt_lines))
+    seq = E.TUMSequence(str(d))
+    assert len(seq) == 3 and seq.color_paths[1].endswith("2.png")
+    img, dep, T = seq[1]
+    assert img.shape == (3, 4, 6) and abs(img[0, 0, 0].item() - 80 / 255) < 1e-6
+    assert abs(dep[0, 0].item() - 3.0) < 1e-6
+    assert torch.allclose(T[:3, 3], torch.tensor([-0.2, 0.0, 0.0]))      # inverse of the camera-to-world pose
+
+
+def test_eval_ate_and_rendering_drivers(tmp_path):
+    class F_:
+        pass
+    g = torch.Generator().manual_seed(4)
+    frames = []
+    for i in range(8):
+        f = F_()
+        f.uid = i
+        Tg = torch.eye(4)
+        Tg[:3, 3] = torch.randn(3, generator=g)
+        f.T_gt = Tg
+        f.T = Tg.clone()
+        f.T[:3, 3] += 0.01 * torch.randn(3, generator=g)
+        frames.append(f)
+    rmse = E.eval_ate(frames, [0, 2, 4, 6, 7], save_dir=str(tmp_path), final=True, monocular=False)
+    assert 0 < rmse < 0.05 and (tmp_path / "plot" / "stats_final.json").exists()
+    gt = [torch.rand(3, 16, 20, generator=g) for _ in range(8)]
+    dataset = [(im, None, None) for im in gt]
+
+    def render_fn(frame, gaussians, pipe, bg):
+        return {"render": gt[frame.uid] * 0.9}
+    out = E.eval_rendering(frames, None, dataset, render_fn, None, None, kf_indices=[0], interval=5)
+    assert out["mean_lpips"] is None and 15 < out["mean_psnr"] < 40 and 0.8 < out["mean_ssim"] < 1.0
