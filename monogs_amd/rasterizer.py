@@ -182,6 +182,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(means3D_c, sh_c, col_c, op_c, sc_c, rot_c, cov_c, view, proj, praw,
                               campos, bg, geom, bins)
         ctx.mark_non_differentiable(radii, n_touched)
+        # undefined output gradients stay None (otherwise autograd fills three zero tensors -
+        # two of them N ints - before every backward)
+        ctx.set_materialize_grads(False)
         return color, radii, depth, opacity, n_touched
 
     @staticmethod

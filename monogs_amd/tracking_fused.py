@@ -46,6 +46,8 @@ class _TrackingLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
+        if grad_out is None:
+            return (None,) * 8
         image_c, opa_c, gt_c, mask_c, exposure_a, exposure_b, partial, scalars = ctx.saved_tensors
         dev = image_c.device
         lib = _cabi.lib()
@@ -161,6 +163,8 @@ class _MappingLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
+        if grad_out is None:
+            return (None,) * 12
         image_c, depth_c, gt_c, gtd_c, mask_c, exposure_a, exposure_b, partial = ctx.saved_tensors
         eps, w_rgb, w_depth, thr, apply_exposure, HW, has_depth = ctx.consts
         dev = image_c.device

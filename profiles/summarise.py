@@ -1,0 +1,58 @@
+"""Summarise a profiles/collect.sh run: per-kernel duration table (from --stats) and HBM
+traffic per launch from the FETCH_SIZE / WRITE_SIZE passes, corrected as
+/opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes for gfx950:
+bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (FETCH_SIZE is in KB and counts half of the bytes
+of wide coalesced loads)."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+out = sys.argv[1]
+
+
+def find(sub, pat):
+    f = glob.glob(f"{out}/{sub}/**/*{pat}", recursive=True)
+    return f[0] if f else None
+
+
+def short(name):
+    n = name.replace("void ", "").replace("mgs::", "")
+    return n.split("(")[0]
+
+
+stats = find("stats", "kernel_stats.csv")
+rows = list(csv.DictReader(open(stats)))
+with open(f"{out}/kernel_stats.csv", "w") as fh:
+    fh.write("kernel,calls,avg_us,total_ms,percent\n")
+    for r in rows:
+        fh.write(f"{short(r['Name'])},{r['Calls']},{float(r['AverageNs']) / 1e3:.2f},"
+                 f"{float(r['TotalDurationNs']) / 1e6:.3f},{float(r['Percentage']):.2f}\n")
+
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for sub, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    f = find(sub, "counter_collection.csv")
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == ctr:
+            agg[short(r["Kernel_Name"])][ctr].append(float(r["Counter_Value"]))
+traffic = {}
+with open(f"{out}/pmc_fetch_write_per_kernel.txt", "w") as fh:
+    fh.write("kernel launches FETCH_SIZE_KB WRITE_SIZE_KB traffic_MB=(2*FETCH+WRITE)*1024 uncorrected_MB\n")
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1].get("FETCH_SIZE", [0]))):
+        if k.startswith("at::") or "rocclr" in k:
+            continue
+        fe = sum(v["FETCH_SIZE"]) / max(1, len(v["FETCH_SIZE"]))
+        wr = sum(v["WRITE_SIZE"]) / max(1, len(v["WRITE_SIZE"]))
+        traffic[k] = int((2 * fe + wr) * 1024)
+        fh.write(f"{k} {len(v['FETCH_SIZE'])} {fe:.1f} {wr:.1f} {(2 * fe + wr) * 1024 / 1e6:.1f} {(fe + wr) * 1024 / 1e6:.1f}\n")
+names = {"k_blend_bwd<false>": "blend_bwd", "k_blend_fwd": "blend_fwd", "k_preprocess_bwd": "preprocess_bwd",
+         "k_preprocess": "preprocess", "k_tile_sort<1024, 0>": "tile_sort", "k_bin_lds": "bin_emit"}
+json.dump({"workload": "SYN-C 300000 @ 640x480",
+           "source": "profiles/collect.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+           "correction": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes: gfx950 FETCH_SIZE counts half of wide "
+                         "coalesced loads (MI355X_MICROARCH.md, HBM)",
+           "bytes_per_launch": {names[k]: v for k, v in traffic.items() if k in names}},
+          open(f"{out}/pmc_traffic.json", "w"), indent=1)
+print(open(f"{out}/kernel_stats.csv").read())
+print(open(f"{out}/pmc_fetch_write_per_kernel.txt").read())
