@@ -184,8 +184,8 @@ __global__ __launch_bounds__(64, 6) void k_blend_bwd(KP P, KB B) {
       const float4 qa = src[0], qb = src[1];
       const float4 q2 = src[2];
       s_r0[lane] = make_float4(qa.x, qa.y, -0.5f * kLog2eB * qb.x, -kLog2eB * qb.y);
-      s_r1[lane] = make_float4(-0.5f * kLog2eB * qb.z, qa.w, qa.z, q2.x);
-      s_r2[lane] = make_float2(q2.y, q2.z);
+      s_r1[lane] = make_float4(-0.5f * kLog2eB * qb.z, qa.w, q2.x, q2.y);   // (C', opacity, r, g)
+      s_r2[lane] = make_float2(q2.z, qa.z);                                  // (b, depth)
       if constexpr (SKETCH) {
         const float4* cj = reinterpret_cast<const float4*>(B.splat_jac + (size_t)id * 36);
 #pragma unroll
@@ -265,7 +265,16 @@ __global__ __launch_bounds__(64, 6) void k_blend_bwd(KP P, KB B) {
   const bool wextra = lane == 31 || lane == 63;
   const int wofs = wextra ? (lane == 31 ? 8 : 9)
                           : ((lane & 7) == 0 ? ((lane >> 5) & 1) + 2 * ((lane >> 4) & 1) + 4 * ((lane >> 3) & 1) : -1);
-  const float fx[2] = {(float)qx, (float)(qx + 8)}, fy[2] = {(float)qy, (float)(qy + 8)};
+  // Packed operands: the per-quadrant body is written on float2 values so that it maps onto
+  // v_pk_{add,mul,fma}_f32 without register shuffles (measured on gfx950: a packed FMA issues
+  // in about the time of a scalar one, so pairs of independent FMAs halve their issue cost).
+  v2f Pq[4], G01[4], G2d[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    Pq[q] = v2f{(float)(qx + 8 * (q & 1)), (float)(qy + 8 * (q >> 1))};
+    G01[q] = v2f{g0[q], g1[q]};
+    G2d[q] = v2f{g2[q], gd[q]};
+  }
 
   unsigned long long written = 0ull;
   for (int j = 0; j < nb; j++) {
@@ -273,17 +282,18 @@ __global__ __launch_bounds__(64, 6) void k_blend_bwd(KP P, KB B) {
     const unsigned int m = __builtin_amdgcn_readfirstlane(s_mask[j]);
     if (m == 0u) continue;
     const float4 u = s_r0[j], v = s_r1[j];
-    const float2 cgb = s_r2[j];
+    const float2 bd2 = s_r2[j];
+    const v2f mu = {u.x, u.y}, RG = {v.z, v.w}, BD = {bd2.x, bd2.y};
     const int idx = base + j;
-    float r[10];
-#pragma unroll
-    for (int i = 0; i < 10; i++) r[i] = 0.f;
+    // pixel sums of this splat: S1 | (Sx, Sy) | (Sxx, Sxy) | Syy | (Rr, Rg) | (Rb, Rd)
+    float r0 = 0.f, r5 = 0.f;
+    v2f R12 = {0.f, 0.f}, R34 = {0.f, 0.f}, R67 = {0.f, 0.f}, R89 = {0.f, 0.f};
     bool any = false;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       if (!(m & (1u << q))) continue;                 // wave-uniform
-      const float dx = u.x - fx[q & 1], dy = u.y - fy[q >> 1];
-      const float pw = dx * (u.z * dx + u.w * dy) + v.x * dy * dy;
+      const v2f d = mu - Pq[q];
+      const float pw = d.x * (u.z * d.x + u.w * d.y) + v.x * d.y * d.y;
       const float ar = v.y * __builtin_amdgcn_exp2f(pw);
       const float al = fminf(kAlphaMax, ar);
       const bool k = idx < last[q] && pw <= 0.f && al >= kAlphaMin;
@@ -291,20 +301,26 @@ __global__ __launch_bounds__(64, 6) void k_blend_bwd(KP P, KB B) {
       any = true;
       const float ae = k ? al : 0.f;
       const float w = ae * T[q];
-      const float gc = g0[q] * v.w + g1[q] * cgb.x + g2[q] * cgb.y + gd[q] * v.z;   // g . c
+      const v2f cc = __builtin_elementwise_fma(G2d[q], BD, G01[q] * RG);
+      const float gc = cc.x + cc.y;                   // g . c
       gS[q] -= w * gc;
       const float om = 1.f - ae;
       const float ro = __builtin_amdgcn_rcpf(om);
       const float dA = T[q] * gc - ro * gS[q];
       T[q] *= om;
       const float Wt = k ? ar * dA : 0.f;
-      const float Wx = Wt * dx, Wy = Wt * dy;
-      r[0] += Wt; r[1] += Wx; r[2] += Wy;
-      r[3] += Wx * dx; r[4] += Wx * dy; r[5] += Wy * dy;
-      r[6] += w * g0[q]; r[7] += w * g1[q]; r[8] += w * g2[q]; r[9] += w * gd[q];
+      const v2f Wxy = v2f{Wt, Wt} * d;                // (W dx, W dy)
+      r0 += Wt;
+      R12 += Wxy;
+      R34 = __builtin_elementwise_fma(v2f{Wxy.x, Wxy.x}, d, R34);
+      r5 = __builtin_fmaf(Wxy.y, d.y, r5);
+      const v2f ww = {w, w};
+      R67 = __builtin_elementwise_fma(ww, G01[q], R67);
+      R89 = __builtin_elementwise_fma(ww, G2d[q], R89);
       if constexpr (SKETCH) {
         // J_t += W (c0 dx + c1 dy + c2 dx^2 + c3 dx dy + c4 dy^2) + (w dL/dD) c5
-        const float X3 = Wx * dx, X4 = Wx * dy, X5 = Wy * dy, X6 = w * gd[q];
+        const float Wx = Wxy.x, Wy = Wxy.y;
+        const float X3 = Wx * d.x, X4 = Wx * d.y, X5 = Wy * d.y, X6 = w * G2d[q].y;
         const float* cf = reinterpret_cast<const float*>(&s_coef[j][0]);
 #pragma unroll
         for (int t = 0; t < 6; t++)
@@ -316,6 +332,7 @@ __global__ __launch_bounds__(64, 6) void k_blend_bwd(KP P, KB B) {
       // the ten wave totals land in ten different lanes; each stores its own dword of the
       // pair's record (slot of splat j broadcast from lane j): one store instruction per splat
       float mres, eres;
+      float r[10] = {r0, R12.x, R12.y, R34.x, R34.y, r5, R67.x, R67.y, R89.x, R89.y};
       wave_sum10_scatter(r, b3mask, mres, eres);
       float* dst = reinterpret_cast<float*>(B.pair_grad) + (size_t)__builtin_amdgcn_readlane(slot, j) * 12;
       if (wofs >= 0) dst[wofs] = wextra ? eres : mres;
