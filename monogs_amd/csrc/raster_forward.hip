@@ -489,7 +489,8 @@ template <int CAP, int MIN_N>
 __global__ __launch_bounds__(256) void k_tile_sort(KP P) {
   __shared__ unsigned long long s_key[CAP];
   __shared__ unsigned int s_val[CAP];
-  const int tile = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
+  for (int tile = blockIdx.x; tile < P.T; tile += gridDim.x) {
   int start = P.tile_offset[tile], end = P.tile_offset[tile + 1];
   start = min(start, P.cap); end = min(end, P.cap);
   const int n = end - start;
@@ -498,15 +499,17 @@ __global__ __launch_bounds__(256) void k_tile_sort(KP P) {
     for (int i = tid; i < ns; i += 256)
       if (s0 + i < P.max_segs) P.seg_tile[s0 + i] = tile;
   }
-  if (n <= 1 || n <= MIN_N || (MIN_N == 0 && n > CAP)) return;
+  if (n <= 1 || n <= MIN_N || (MIN_N == 0 && n > CAP)) continue;   // workgroup-uniform
   unsigned long long* gk = P.keys + start;
   unsigned int* gv = P.payload + start;
   if (n <= CAP) {
+    __syncthreads();      // the previous tile of this workgroup is done with the LDS arrays
     for (int i = tid; i < n; i += 256) { s_key[i] = gk[i]; s_val[i] = gv[i]; }
     bitonic_sort<true>(s_key, s_val, n, tid);
     for (int i = tid; i < n; i += 256) { gk[i] = s_key[i]; gv[i] = s_val[i]; }
   } else {
     bitonic_sort<false>(gk, gv, n, tid);
+  }
   }
 }
 
@@ -750,7 +753,8 @@ int launch_forward_blend(const KP& P, hipStream_t st) {
     launch("bin_emit", k_bin, dim3((P.N + 255) / 256), dim3(256), st, P, 1);
   }
   launch("tile_sort", k_tile_sort<1024, 0>, dim3(P.T), dim3(256), st, P);
-  launch("tile_sort_big", k_tile_sort<4096, 1024>, dim3(P.T), dim3(256), st, P);
+  // crowded tiles are rare: a small grid walks the tile list instead of T mostly idle workgroups
+  launch("tile_sort_big", k_tile_sort<4096, 1024>, dim3(min(P.T, 256)), dim3(256), st, P);
   launch("blend_fwd", k_blend_fwd, dim3(grid_pad(4 * P.T, kFwdChunk)), dim3(64), st, P);
   return check_launch();
 }
