@@ -10,8 +10,14 @@ unpinned) and is ABSENT from the reference tree, so the algorithm restated here
 follows the published 3DGS / MonoGS algorithm and the in-tree call sites and
 consumers; every behavioural constant is listed in `CONSTANTS` below.
 
-PARITY UNPINNED: the reference holds no golden vector, test or fixture for the
-rasteriser.  What *is* pinned against the reference's own code
+PARITY PARTLY PINNED: the reference holds no golden vector, test or fixture for the
+rasteriser, but it does hold its authors' own restatement of the
+per-Gaussian projection / EWA splat and of the alpha rule - the OpenGL viewer shaders
+gui/gl_render/shaders/gau_vert.glsl:60-154 and gau_frag.glsl:20-26.  oracle/glsl_ewa.py
+follows them line by line and tests/test_cpu_oracle.py checks `project()` (2-D covariance,
+conic) and the per-pixel alpha of `rasterize()` against it to 1e-9.  Tile assignment,
+the stopping / n_touched thresholds, the near-plane cull and the whole backward remain
+UNPINNED against the CUDA extension.  Also pinned against the reference's own code
 (see tests/golden/make_golden.py) are the pieces that exist in-tree: the camera
 matrices (`utils/camera_utils.py:94-104`, `graphics_utils.py:56-77`), the 3-D
 covariance (`general_utils.py:114-149`), SH evaluation (`sh_utils.py:55-118`),
