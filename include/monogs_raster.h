@@ -313,6 +313,15 @@ typedef struct mgs_adam_group {
 int32_t mgs_adam_step_multi(const mgs_adam_group* groups, int32_t num_groups, double beta1,
                             double beta2, double eps, void* stream);
 
+/* Keyframe-parallel mapping: one launch packs this rank's parameter gradients
+ * and the densification statistics of its view (gaussian_model.py:693-697:
+ * ||means2D.grad[:, :2]|| where radii > 0, and the visibility count) into the flat buffer that
+ * is all-reduced over RCCL: flat = [grad_0 | ... | grad_{k-1} | grad-norm stat [N] | visible [N]].
+ * radii is copied to radii_out (all-reduced with max). */
+int32_t mgs_pack_mapping_grads(const float* const* grads, const int64_t* numels, int32_t num_grads,
+                               const float* means2D_grad, const int32_t* radii,
+                               int64_t num_gaussians, float* flat, int32_t* radii_out, void* stream);
+
 /* Rebuild plan of GaussianModel.densify_and_prune (gaussian_model.py:674-691 =
  * densify_and_clone :636-672, densify_and_split :598-634, prune_points :540-556) or, with
  * prune_mask != NULL, of prune_points(mask) alone.  Rows of the rebuilt arrays, in the

@@ -22,7 +22,7 @@ EXPORTS = (
     "mgs_tracking_loss_backward", "mgs_lm_solve_step", "mgs_mapping_loss_forward",
     "mgs_mapping_loss_backward", "mgs_camera_from_pose", "mgs_tracking_iteration",
     "mgs_adam_step_multi", "mgs_map_plan_blocks", "mgs_map_plan_count", "mgs_map_plan_emit",
-    "mgs_map_gather",
+    "mgs_map_gather", "mgs_pack_mapping_grads",
 )
 
 _fp = C.c_void_p  # device pointers travel as plain addresses
@@ -144,6 +144,9 @@ def lib():
     L.mgs_adam_step_multi.restype = C.c_int32
     L.mgs_adam_step_multi.argtypes = [C.POINTER(AdamGroup), C.c_int32, C.c_double, C.c_double, C.c_double,
                                       C.c_void_p]
+    L.mgs_pack_mapping_grads.restype = C.c_int32
+    L.mgs_pack_mapping_grads.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32, C.c_void_p,
+                                         C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.mgs_map_plan_blocks.restype = C.c_int32
     L.mgs_map_plan_blocks.argtypes = [C.c_int32]
     for fn in (L.mgs_map_plan_count, L.mgs_map_plan_emit):

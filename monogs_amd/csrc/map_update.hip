@@ -234,6 +234,45 @@ __global__ __launch_bounds__(256) void k_gather_rows(GatherPack G) {
   }
 }
 
+// ---------------------------------------------------------------------------------
+// Keyframe-parallel mapping: pack this rank's gradients and densification
+// statistics into the flat all-reduce buffer in ONE launch:
+//   flat = [grad_0 | grad_1 | ... | ||means2D.grad[:, :2]|| masked by visibility | visibility]
+// (gaussian_model.py:693-697: the statistics are formed per view BEFORE the reduction).
+struct PackPack {
+  const float* src[MGS_ADAM_MAX_GROUPS];
+  long long end[MGS_ADAM_MAX_GROUPS];     // inclusive scan of numel
+  int n;
+  const float* means2D_grad;              // [N,3]
+  const int* radii;                       // [N]
+  int* radii_out;                         // [N]
+  long long N;
+  float* flat;
+};
+
+__global__ __launch_bounds__(256) void k_pack_grads(PackPack A) {
+  const long long total = A.end[A.n - 1] + 2 * A.N;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    float v;
+    if (e < A.end[A.n - 1]) {
+      int grp = 0;
+      while (grp < A.n - 1 && e >= A.end[grp]) grp++;
+      v = A.src[grp][e - (grp ? A.end[grp - 1] : 0)];
+    } else {
+      const long long i = e - A.end[A.n - 1];
+      if (i < A.N) {
+        const bool vis = A.radii[i] > 0;
+        const float gx = A.means2D_grad[3 * i], gy = A.means2D_grad[3 * i + 1];
+        v = vis ? sqrtf(gx * gx + gy * gy) : 0.f;
+        A.radii_out[i] = A.radii[i];
+      } else {
+        v = A.radii[i - A.N] > 0 ? 1.f : 0.f;
+      }
+    }
+    A.flat[e] = v;
+  }
+}
+
 }  // namespace mgs
 
 using namespace mgs;
@@ -267,6 +306,29 @@ int32_t mgs_adam_step_multi(const mgs_adam_group* groups, int32_t num_groups, do
   const long long want = (chunks + 255) / 256;
   const int grid = (int)(want < 1 ? 1 : (want > 65535 * 16 ? 65535 * 16 : want));
   launch("adam_multi", k_adam_multi, dim3(grid), dim3(256), (hipStream_t)stream, A, chunks, vec);
+  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+}
+
+int32_t mgs_pack_mapping_grads(const float* const* grads, const int64_t* numels, int32_t num_grads,
+                               const float* means2D_grad, const int32_t* radii, int64_t num_gaussians,
+                               float* flat, int32_t* radii_out, void* stream) {
+  if (!grads || !numels || num_grads < 1 || num_grads > MGS_ADAM_MAX_GROUPS || !means2D_grad || !radii ||
+      num_gaussians < 1 || !flat || !radii_out)
+    return MGS_ERR_BAD_ARGUMENT;
+  PackPack A;
+  long long run = 0;
+  for (int i = 0; i < num_grads; i++) {
+    if (!grads[i] || numels[i] < 1) return MGS_ERR_BAD_ARGUMENT;
+    A.src[i] = grads[i];
+    run += numels[i];
+    A.end[i] = run;
+  }
+  A.n = num_grads; A.means2D_grad = means2D_grad; A.radii = radii; A.radii_out = radii_out;
+  A.N = num_gaussians; A.flat = flat;
+  const long long total = run + 2 * num_gaussians;
+  long long want = (total + 255) / 256;
+  if (want > 8192) want = 8192;
+  launch("pack_grads", k_pack_grads, dim3((unsigned)want), dim3(256), (hipStream_t)stream, A);
   return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
 }
 

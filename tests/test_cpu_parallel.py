@@ -30,7 +30,8 @@ def _worker(rank, world, port, ret):
     for i, p in enumerate(params):
         want = sum(grads[r][i] for r in range(world))
         ok &= torch.allclose(p.grad, want, atol=1e-6) and p.grad.is_contiguous()
-    want_stat = sum(torch.linalg.norm(grads[r][5][:, :2], dim=-1) for r in range(world))
+    # add_densification_stats (gaussian_model.py:693-697) only touches visible Gaussians
+    want_stat = sum(torch.linalg.norm(grads[r][5][:, :2], dim=-1) * (grads[r][6] > 0) for r in range(world))
     want_den = sum((grads[r][6] > 0).float() for r in range(world))
     want_rad = torch.stack([grads[r][6] for r in range(world)]).max(0).values
     ok &= torch.allclose(stat, want_stat, atol=1e-5) and torch.equal(denom, want_den)
@@ -58,4 +59,4 @@ def test_flat_gradient_bucket_single_process_roundtrip():
     b = FlatGradBucket(params)
     stat, denom, radii = b.all_reduce(torch.ones(10, 3), torch.arange(10, dtype=torch.int32))
     assert all(torch.equal(p.grad, r) for p, r in zip(params, ref))
-    assert torch.allclose(stat, torch.full((10,), 2 ** 0.5)) and denom.sum() == 9 and radii.max() == 9
+    assert torch.allclose(stat[1:], torch.full((9,), 2 ** 0.5)) and stat[0] == 0 and denom.sum() == 9 and radii.max() == 9

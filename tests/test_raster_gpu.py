@@ -1042,3 +1042,26 @@ def test_densify_and_prune_matches_the_reference_restatement(built, fused, max_s
     got2 = _state_of(m, attr, cpu)
     for k, w in want2.items():
         assert got2[k].shape == w.shape and torch.equal(got2[k], w.to(got2[k].dtype)), k
+
+
+def test_gradient_bucket_pack_kernel_matches_torch(built):
+    """FlatGradBucket.pack on the GPU (one HIP launch) against the PyTorch formulation of
+    gaussian_model.py:693-697 + torch.cat."""
+    from monogs_amd.parallel import FlatGradBucket
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    N = 4099
+    shapes = [(N, 3), (N, 1, 3), (N, 1), (N, 3), (N, 4)]
+    params = [torch.zeros(s, device=dev) for s in shapes]
+    for p in params:
+        p.grad = torch.randn(p.shape, generator=g).to(dev)
+    m2d = torch.randn(N, 3, generator=g).to(dev)
+    radii = torch.randint(-1, 4, (N,), generator=g).int().to(dev)
+    b = FlatGradBucket(params)
+    want = torch.cat([p.grad.reshape(-1) for p in params]
+                     + [torch.where(radii > 0, torch.linalg.norm(m2d[:, :2], dim=-1), torch.zeros(N, device=dev)),
+                        (radii > 0).float()])
+    stat, denom, rad = b.all_reduce(m2d, radii)          # single process: pack + unpack
+    assert torch.allclose(b.flat, want, rtol=1e-6, atol=0)
+    assert torch.equal(rad, radii) and torch.equal(denom, (radii > 0).float())
+    assert params[4].grad.data_ptr() == b.flat[sum(p.numel() for p in params[:4]):].data_ptr()
