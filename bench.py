@@ -72,7 +72,7 @@ def bench_tracking(sc, dev, iters):
     out = {}
     from monogs_amd.tracking_native import NativeTracker
     for mode in ("first_order", "first_order_fused", "first_order_native", "second_order",
-                 "second_order_fused"):
+                 "second_order_fused", "second_order_native"):
         vp = view(SE3_exp(torch.tensor([0.01, -0.008, 0.006, 0.002, -0.003, 0.002])))
         vp.original_image = target
         vp.rgb_pixel_mask_mapping = (target.sum(0) > 0.01).view(1, H, W)
@@ -83,6 +83,10 @@ def bench_tracking(sc, dev, iters):
         if mode == "first_order_native":
             n = 4 * iters
             trk = NativeTracker(vp, gauss, bg)
+        if mode == "second_order_native":
+            n = 2 * iters
+            trk = NativeTracker(vp, gauss, bg)
+            trk.enable_second_order(stack_dim=16, sketch_dim=64, initial_lambda=1e-3)
 
         def it():
             if mode == "first_order":
@@ -91,6 +95,8 @@ def bench_tracking(sc, dev, iters):
                 tracking_step_first_order_fused(vp, gauss, fopt, bg)
             elif mode == "first_order_native":
                 trk.step()
+            elif mode == "second_order_native":
+                trk.step_second_order()
             else:
                 tracking_step_second_order(vp, gauss, bg, lambda_=1e-3, repeat_dim=1, stack_dim=16,
                                            sketch_dim=64, generator=gen,
@@ -103,7 +109,7 @@ def bench_tracking(sc, dev, iters):
             it()
         torch.cuda.synchronize()
         out[mode + "_iters_per_s"] = round(n / (time.perf_counter() - t0), 2)
-        if mode == "first_order_native" and not trk.check_capacity():
+        if mode.endswith("native") and not trk.check_capacity():
             raise RuntimeError("native tracking bench overflowed its pair capacity")
     out["map"] = f"frozen SYN-C map, {sc.means3D.shape[0]} Gaussians @ {W}x{H}"
     return out

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MGS_ABI_VERSION 2
+#define MGS_ABI_VERSION 3
 
 typedef enum mgs_status {
   MGS_OK = 0,
@@ -122,9 +122,20 @@ typedef struct mgs_backward_args {
   const int32_t* sketch_indices;  /* [stack,H,W] slice for this repeat, bucket id or -1 */
   float* grad_sketch_dtau;        /* [stack,sketch,6] */
   void* sketch_ws;                /* sketch_bytes of scratch (sketch_mode != 0) */
+  /* compact alternative to sketch_indices (the buckets of one repeat are disjoint, so one
+   * int per pixel suffices): [H,W] = stack * sketch_dim + bucket, or -1.  Used when
+   * sketch_indices is NULL. */
+  const int32_t* sketch_bucket_flat;
 } mgs_backward_args;
 
 int32_t mgs_abi_version(void);
+/* sizeof() of the argument structs, in declaration order (0 = mgs_raster_shape,
+ * 1 = mgs_workspace_sizes, 2 = mgs_forward_args, 3 = mgs_backward_args, 4 = mgs_pose_adam_args,
+ * 5 = mgs_mapping_loss_args, 6 = mgs_lm_step_args, 7 = mgs_tracking_loss_args,
+ * 8 = mgs_tracking_iter_args, 9 = mgs_sketch_residual_args, 10 = mgs_tracking_so_args,
+ * 11 = mgs_adam_group, 12 = mgs_map_plan_args, 13 = mgs_gather_tensor, 14 = mgs_map_gather_args);
+ * -1 for an unknown index.  Lets a foreign-language binding verify its struct mirrors. */
+int32_t mgs_struct_size(int32_t which);
 const char* mgs_status_string(int32_t status);
 
 /* Sizes/offsets of the workspaces for `shape` (uses shape->pair_capacity). */
@@ -222,6 +233,17 @@ typedef struct mgs_lm_step_args {
   float* exposure_a;    /* [1] or NULL */
   float* exposure_b;    /* [1] or NULL */
   float* x_out;         /* [8] */
+  /* optional extensions (all NULL / 0 for the plain solve) */
+  const float* sj_tau;       /* [rows, 6]: used with sj_exposure when SJ == NULL */
+  const float* sj_exposure;  /* [rows, 2] */
+  float* lm_state;           /* [4] device-resident trust-region state {lambda, previous loss,
+                                has_previous, converged}; when given, `lambda` is ignored and the
+                                rule of utils/slam_frontend.py:536-545 runs on the device first:
+                                loss < previous ? lambda = max(lambda / decrease, min_lambda)
+                                                : lambda = min(lambda * increase, max_lambda) */
+  const float* loss;         /* [1] current ||residual||_1 (lm_state only) */
+  float increase_factor, decrease_factor, min_lambda, max_lambda;
+  float converged_threshold; /* lm_state[3] = |x| < threshold (slam_frontend.py:699) */
 } mgs_lm_step_args;
 
 int32_t mgs_lm_solve_step(const mgs_lm_step_args* args, void* stream);
@@ -287,6 +309,66 @@ typedef struct mgs_tracking_iter_args {
 
 int32_t mgs_tracking_iteration(const mgs_tracking_iter_args* args, void* stream);
 
+
+
+/* ---- native second-order (sketched Levenberg-Marquardt) tracking iteration ----------------
+ * utils/slam_frontend.py:455-710 with in_second_order = True.
+ *
+ * mgs_sketch_assign: the CountSketch bookkeeping of :269-338 as one kernel.  The reference
+ * draws torch.randperm(H*W) and cuts its first chunk*stack*sketch entries (chunk =
+ * H*W / (stack*sketch)) into disjoint buckets; here pixel p gets position q = pi_key(p) of a
+ * keyed pseudo-random PERMUTATION of [0, H*W) (invertible multiply / xor-shift rounds on
+ * ceil(log2 HW) bits with cycle walking), bucket[p] = q / chunk if q < chunk*stack*sketch else
+ * -1, and weights[p] = +-1 from a hash bit.  Same structure (disjoint buckets of exactly
+ * `chunk` pixels), no sort, no index tensors. */
+int32_t mgs_sketch_assign(int64_t num_pixels, int32_t stack_dim, int32_t sketch_dim, uint64_t key,
+                          int32_t* bucket, float* weights, void* stream);
+
+/* Sketched monocular tracking residual (utils/slam_utils.py:188-205 + Huber :58-75 + the
+ * bucket sums of slam_frontend.py:636-650 and ApplyExposure's sketched Jacobian
+ * slam_utils.py:150-185), one pass over the image:
+ *   r_c = opacity * mask * ((|a|+eps) image_c + b - gt_c);  l1 = sum |r_c|
+ *   weighted_p = weights_p / (HW / (stack*sketch)) * sum_c Huber(r_c)
+ *   Sf[b] += weighted_p;  sj_exposure[b] += d weighted_p / d(a, b);  grad_image = d weighted_p / d image
+ * Sf / sj_exposure / l1 must be zero on entry (they are accumulated with atomics). */
+typedef struct mgs_sketch_residual_args {
+  const float* image;        /* [3,H,W] */
+  const float* opacity;      /* [1,H,W] */
+  const float* gt;           /* [3,H,W] */
+  const float* mask;         /* [1,H,W] float 0/1 or NULL */
+  const float* exposure_a;
+  const float* exposure_b;
+  float exposure_eps, huber_delta;
+  int64_t num_pixels;
+  int32_t stack_dim, sketch_dim;
+  const int32_t* bucket;     /* from mgs_sketch_assign */
+  const float* weights;
+  float* grad_image;         /* [3,H,W] out */
+  float* Sf;                 /* [stack*sketch] accumulated */
+  float* sj_exposure;        /* [stack*sketch, 2] accumulated */
+  float* l1;                 /* [1] accumulated */
+} mgs_sketch_residual_args;
+
+int32_t mgs_sketch_residual(const mgs_sketch_residual_args* args, void* stream);
+
+/* One second-order iteration as a fixed launch sequence (no host round trip): camera
+ * matrices from T -> forward -> zero accumulators -> mgs_sketch_assign(key) ->
+ * mgs_sketch_residual -> pose-only backward in sketch mode (grad_sketch_dtau via the compact
+ * bucket map) -> mgs_lm_solve_step with the device-resident trust-region state.
+ * `base` as for mgs_tracking_iteration (its adam block is unused except T / exposure);
+ * `accum` holds stack*sketch*9 + 4 floats: Sf[d] | sj_exposure[d,2] | sj_tau[d,6] | l1, pad. */
+typedef struct mgs_tracking_so_args {
+  mgs_tracking_iter_args base;
+  int32_t stack_dim, sketch_dim;
+  uint64_t key;              /* changes every iteration */
+  int32_t* bucket;           /* [H*W] scratch */
+  float* weights;            /* [H*W] scratch */
+  float* accum;
+  void* sketch_ws;           /* sketch_bytes of backward scratch */
+  mgs_lm_step_args lm;       /* SJ / Sf / sj_* / loss fields are filled in by the call */
+} mgs_tracking_so_args;
+
+int32_t mgs_tracking_iteration_second_order(const mgs_tracking_so_args* args, void* stream);
 
 /* ---- map maintenance on the device ---------------------------------- */
 

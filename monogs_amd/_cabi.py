@@ -12,17 +12,18 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmonogs_raster.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 EXPORTS = (
-    "mgs_abi_version", "mgs_status_string", "mgs_raster_workspace_query",
+    "mgs_abi_version", "mgs_struct_size", "mgs_status_string", "mgs_raster_workspace_query",
     "mgs_raster_forward_project", "mgs_raster_forward_blend", "mgs_raster_backward",
     "mgs_knn_scratch_bytes", "mgs_knn_dist2", "mgs_profile_enable", "mgs_profile_read",
     "mgs_pose_adam_step", "mgs_tracking_loss_partial_count", "mgs_tracking_loss_forward",
     "mgs_tracking_loss_backward", "mgs_lm_solve_step", "mgs_mapping_loss_forward",
     "mgs_mapping_loss_backward", "mgs_camera_from_pose", "mgs_tracking_iteration",
     "mgs_adam_step_multi", "mgs_map_plan_blocks", "mgs_map_plan_count", "mgs_map_plan_emit",
-    "mgs_map_gather", "mgs_pack_mapping_grads",
+    "mgs_map_gather", "mgs_pack_mapping_grads", "mgs_sketch_assign", "mgs_sketch_residual",
+    "mgs_tracking_iteration_second_order",
 )
 
 _fp = C.c_void_p  # device pointers travel as plain addresses
@@ -54,7 +55,8 @@ class BackwardArgs(C.Structure):
         "grad_color", "grad_depth", "bwd", "grad_means3D", "grad_means2D", "grad_colors",
         "grad_opacities", "grad_scales", "grad_rotations", "grad_cov3D", "grad_tau")]
         + [("sketch_mode", C.c_int32), ("sketch_dim", C.c_int32), ("stack_dim", C.c_int32),
-           ("sketch_indices", _fp), ("grad_sketch_dtau", _fp), ("sketch_ws", _fp)])
+           ("sketch_indices", _fp), ("grad_sketch_dtau", _fp), ("sketch_ws", _fp),
+           ("sketch_bucket_flat", _fp)])
 
 
 class PoseAdamArgs(C.Structure):
@@ -76,7 +78,10 @@ class MappingLossArgs(C.Structure):
 
 class LMStepArgs(C.Structure):
     _fields_ = [("SJ", _fp), ("Sf", _fp), ("rows", C.c_int32), ("lam", C.c_float), ("T", _fp),
-                ("exposure_a", _fp), ("exposure_b", _fp), ("x_out", _fp)]
+                ("exposure_a", _fp), ("exposure_b", _fp), ("x_out", _fp),
+                ("sj_tau", _fp), ("sj_exposure", _fp), ("lm_state", _fp), ("loss", _fp),
+                ("increase_factor", C.c_float), ("decrease_factor", C.c_float),
+                ("min_lambda", C.c_float), ("max_lambda", C.c_float), ("converged_threshold", C.c_float)]
 
 
 class TrackingLossArgs(C.Structure):
@@ -89,6 +94,19 @@ class TrackingIterArgs(C.Structure):
     _fields_ = [("fwd", ForwardArgs), ("bwd", _fp), ("grad_image", _fp), ("grad_tau", _fp),
                 ("grad_exposure", _fp), ("one", _fp), ("loss", TrackingLossArgs),
                 ("adam", PoseAdamArgs)]
+
+
+class SketchResidualArgs(C.Structure):
+    _fields_ = ([(n, _fp) for n in ("image", "opacity", "gt", "mask", "exposure_a", "exposure_b")]
+                + [("exposure_eps", C.c_float), ("huber_delta", C.c_float), ("num_pixels", C.c_int64),
+                   ("stack_dim", C.c_int32), ("sketch_dim", C.c_int32)]
+                + [(n, _fp) for n in ("bucket", "weights", "grad_image", "Sf", "sj_exposure", "l1")])
+
+
+class TrackingSOArgs(C.Structure):
+    _fields_ = [("base", TrackingIterArgs), ("stack_dim", C.c_int32), ("sketch_dim", C.c_int32),
+                ("key", C.c_uint64), ("bucket", _fp), ("weights", _fp), ("accum", _fp),
+                ("sketch_ws", _fp), ("lm", LMStepArgs)]
 
 
 ADAM_MAX_GROUPS = 8
@@ -144,6 +162,13 @@ def lib():
     L.mgs_adam_step_multi.restype = C.c_int32
     L.mgs_adam_step_multi.argtypes = [C.POINTER(AdamGroup), C.c_int32, C.c_double, C.c_double, C.c_double,
                                       C.c_void_p]
+    L.mgs_sketch_assign.restype = C.c_int32
+    L.mgs_sketch_assign.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]
+    L.mgs_sketch_residual.restype = C.c_int32
+    L.mgs_sketch_residual.argtypes = [C.POINTER(SketchResidualArgs), C.c_void_p]
+    L.mgs_tracking_iteration_second_order.restype = C.c_int32
+    L.mgs_tracking_iteration_second_order.argtypes = [C.POINTER(TrackingSOArgs), C.c_void_p]
     L.mgs_pack_mapping_grads.restype = C.c_int32
     L.mgs_pack_mapping_grads.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32, C.c_void_p,
                                          C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -185,11 +210,20 @@ def lib():
     for fn in (L.mgs_tracking_loss_forward, L.mgs_tracking_loss_backward):
         fn.restype = C.c_int32
         fn.argtypes = [C.POINTER(TrackingLossArgs), C.c_void_p]
+    L.mgs_struct_size.restype = C.c_int32
+    L.mgs_struct_size.argtypes = [C.c_int32]
     if L.mgs_abi_version() != ABI_VERSION:
         raise NativeLibraryError(
             f"ABI mismatch: library {L.mgs_abi_version()} vs binding {ABI_VERSION}")
     _lib = L
     return L
+
+
+def struct_mirrors():
+    """ctypes mirror of every argument struct, in mgs_struct_size() order."""
+    return [RasterShape, WorkspaceSizes, ForwardArgs, BackwardArgs, PoseAdamArgs, MappingLossArgs,
+            LMStepArgs, TrackingLossArgs, TrackingIterArgs, SketchResidualArgs, TrackingSOArgs,
+            AdamGroup, MapPlanArgs, GatherTensor, MapGatherArgs]
 
 
 def check(status: int, what: str) -> None:

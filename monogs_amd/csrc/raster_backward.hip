@@ -426,12 +426,21 @@ __global__ __launch_bounds__(256) void k_sketch_bucket(KP P, KB B) {
     float J[6];
 #pragma unroll
     for (int t = 0; t < 6; t++) J[t] = B.pix_jac[(size_t)t * HW + p];
-    for (int s = 0; s < B.stack_dim; s++) {
-      const int k = B.sketch_idx[(size_t)s * HW + p];
-      if (k >= 0 && k < B.sketch_dim) {
-        float* a = &s_acc[(s * B.sketch_dim + k) * 6];
+    if (B.sketch_flat) {      // one bucket per pixel
+      const int b = B.sketch_flat[p];
+      if (b >= 0 && b < B.stack_dim * B.sketch_dim) {
+        float* a = &s_acc[b * 6];
 #pragma unroll
         for (int t = 0; t < 6; t++) atomicAdd(&a[t], J[t]);
+      }
+    } else {
+      for (int s = 0; s < B.stack_dim; s++) {
+        const int k = B.sketch_idx[(size_t)s * HW + p];
+        if (k >= 0 && k < B.sketch_dim) {
+          float* a = &s_acc[(s * B.sketch_dim + k) * 6];
+#pragma unroll
+          for (int t = 0; t < 6; t++) atomicAdd(&a[t], J[t]);
+        }
       }
     }
   }

@@ -96,6 +96,27 @@ extern "C" {
 
 int32_t mgs_abi_version(void) { return MGS_ABI_VERSION; }
 
+int32_t mgs_struct_size(int32_t which) {
+  switch (which) {
+    case 0: return (int32_t)sizeof(mgs_raster_shape);
+    case 1: return (int32_t)sizeof(mgs_workspace_sizes);
+    case 2: return (int32_t)sizeof(mgs_forward_args);
+    case 3: return (int32_t)sizeof(mgs_backward_args);
+    case 4: return (int32_t)sizeof(mgs_pose_adam_args);
+    case 5: return (int32_t)sizeof(mgs_mapping_loss_args);
+    case 6: return (int32_t)sizeof(mgs_lm_step_args);
+    case 7: return (int32_t)sizeof(mgs_tracking_loss_args);
+    case 8: return (int32_t)sizeof(mgs_tracking_iter_args);
+    case 9: return (int32_t)sizeof(mgs_sketch_residual_args);
+    case 10: return (int32_t)sizeof(mgs_tracking_so_args);
+    case 11: return (int32_t)sizeof(mgs_adam_group);
+    case 12: return (int32_t)sizeof(mgs_map_plan_args);
+    case 13: return (int32_t)sizeof(mgs_gather_tensor);
+    case 14: return (int32_t)sizeof(mgs_map_gather_args);
+    default: return -1;
+  }
+}
+
 const char* mgs_status_string(int32_t status) {
   switch (status) {
     case MGS_OK: return "ok";
@@ -148,7 +169,7 @@ int32_t mgs_raster_backward(const mgs_backward_args* args, void* stream) {
       return MGS_ERR_BAD_ARGUMENT;
   }
   if (args->sketch_mode != 0 &&
-      (!args->sketch_indices || !args->grad_sketch_dtau || !args->sketch_ws ||
+      ((!args->sketch_indices && !args->sketch_bucket_flat) || !args->grad_sketch_dtau || !args->sketch_ws ||
        args->sketch_dim < 1 || args->stack_dim < 1))
     return MGS_ERR_BAD_ARGUMENT;
   const Layout L = make_layout(args->fwd.shape);
@@ -163,6 +184,7 @@ int32_t mgs_raster_backward(const mgs_backward_args* args, void* stream) {
   B.g_tau = args->grad_tau;
   B.sketch_mode = args->sketch_mode; B.sketch_dim = args->sketch_dim; B.stack_dim = args->stack_dim;
   B.sketch_idx = args->sketch_indices; B.g_sketch = args->grad_sketch_dtau;
+  B.sketch_flat = args->sketch_indices ? nullptr : args->sketch_bucket_flat;
   char* sw = (char*)args->sketch_ws;
   B.pix_jac = sw ? (float*)(sw + L.pix_jac) : nullptr;
   B.splat_jac = sw ? (float*)(sw + L.splat_jac) : nullptr;
@@ -198,6 +220,52 @@ int32_t mgs_tracking_iteration(const mgs_tracking_iter_args* args, void* stream)
   A.grad_a = A.exposure_a ? args->grad_exposure : nullptr;
   A.grad_b = A.exposure_b ? args->grad_exposure + 1 : nullptr;
   return mgs_pose_adam_step(&A, stream);
+}
+
+int32_t mgs_tracking_iteration_second_order(const mgs_tracking_so_args* args, void* stream) {
+  if (!args) return MGS_ERR_BAD_ARGUMENT;
+  const mgs_tracking_iter_args& b = args->base;
+  if (!b.bwd || !b.grad_image || !b.grad_tau || !b.adam.T || !b.fwd.viewmatrix || !b.fwd.projmatrix ||
+      b.fwd.shape.pair_capacity < 1 || !args->bucket || !args->weights || !args->accum || !args->sketch_ws ||
+      !args->lm.lm_state || !args->lm.x_out || args->stack_dim < 1 || args->sketch_dim < 1)
+    return MGS_ERR_BAD_ARGUMENT;
+  const int64_t HW = (int64_t)b.fwd.shape.width * b.fwd.shape.height;
+  const int d = args->stack_dim * args->sketch_dim;
+  float* Sf = args->accum;
+  float* sj_exp = Sf + d;
+  float* sj_tau = sj_exp + 2 * (size_t)d;
+  float* l1 = sj_tau + 6 * (size_t)d;
+  int32_t rc = mgs_camera_from_pose(b.adam.T, b.fwd.projmatrix_raw, const_cast<float*>(b.fwd.viewmatrix),
+                                    const_cast<float*>(b.fwd.projmatrix), stream);
+  if (rc != MGS_OK) return rc;
+  if ((rc = mgs_raster_forward_project(&b.fwd, stream)) != MGS_OK) return rc;
+  if ((rc = mgs_raster_forward_blend(&b.fwd, stream)) != MGS_OK) return rc;
+  // Sf, sj_exposure and l1 are accumulated with atomics (sj_tau is zeroed by the backward)
+  if (hipMemsetAsync(Sf, 0, sizeof(float) * 3 * (size_t)d, (hipStream_t)stream) != hipSuccess ||
+      hipMemsetAsync(l1, 0, sizeof(float) * 4, (hipStream_t)stream) != hipSuccess)
+    return MGS_ERR_LAUNCH;
+  if ((rc = mgs_sketch_assign(HW, args->stack_dim, args->sketch_dim, args->key, args->bucket, args->weights,
+                              stream)) != MGS_OK)
+    return rc;
+  mgs_sketch_residual_args R;
+  memset(&R, 0, sizeof(R));
+  R.image = b.fwd.out_color; R.opacity = b.fwd.out_opacity; R.gt = b.loss.gt; R.mask = b.loss.mask;
+  R.exposure_a = b.loss.exposure_a; R.exposure_b = b.loss.exposure_b;
+  R.exposure_eps = b.loss.exposure_eps; R.huber_delta = b.loss.huber_delta; R.num_pixels = HW;
+  R.stack_dim = args->stack_dim; R.sketch_dim = args->sketch_dim;
+  R.bucket = args->bucket; R.weights = args->weights; R.grad_image = b.grad_image;
+  R.Sf = Sf; R.sj_exposure = sj_exp; R.l1 = l1;
+  if ((rc = mgs_sketch_residual(&R, stream)) != MGS_OK) return rc;
+  mgs_backward_args B;
+  memset(&B, 0, sizeof(B));
+  B.fwd = b.fwd; B.grad_color = b.grad_image; B.bwd = b.bwd; B.grad_tau = b.grad_tau;
+  B.sketch_mode = 1; B.sketch_dim = args->sketch_dim; B.stack_dim = args->stack_dim;
+  B.sketch_bucket_flat = args->bucket; B.grad_sketch_dtau = sj_tau; B.sketch_ws = args->sketch_ws;
+  if ((rc = mgs_raster_backward(&B, stream)) != MGS_OK) return rc;
+  mgs_lm_step_args L = args->lm;
+  L.SJ = nullptr; L.sj_tau = sj_tau; L.sj_exposure = sj_exp; L.Sf = Sf; L.rows = d; L.loss = l1;
+  L.T = b.adam.T; L.exposure_a = b.adam.exposure_a; L.exposure_b = b.adam.exposure_b;
+  return mgs_lm_solve_step(&L, stream);
 }
 
 int32_t mgs_profile_enable(int32_t on) {

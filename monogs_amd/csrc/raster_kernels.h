@@ -49,6 +49,7 @@ struct KB {   // backward extras
   float *g_means3D, *g_means2D, *g_colors, *g_opac, *g_scales, *g_rots, *g_cov, *g_tau;
   int sketch_mode, sketch_dim, stack_dim;
   const int* sketch_idx;
+  const int* sketch_flat;   // [H*W] stack * sketch_dim + bucket or -1 (compact alternative)
   float* g_sketch;
   float* pix_jac;          // W*H x 6 per-pixel pose-Jacobian rows (sketch mode)
   float* splat_jac;        // N x 36 per-splat d(xy,conic,depth)/dtau (sketch mode)

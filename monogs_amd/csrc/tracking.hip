@@ -197,8 +197,14 @@ __global__ __launch_bounds__(256) void k_lm_solve_step(mgs_lm_step_args A) {
   for (int i = 0; i < 44; i++) acc[i] = 0.0;
   for (int r = threadIdx.x; r < A.rows; r += 256) {
     float row[8];
+    if (A.SJ) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) row[i] = A.SJ[(size_t)r * 8 + i];
+      for (int i = 0; i < 8; i++) row[i] = A.SJ[(size_t)r * 8 + i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; i++) row[i] = A.sj_tau[(size_t)r * 6 + i];
+      row[6] = A.sj_exposure[(size_t)r * 2]; row[7] = A.sj_exposure[(size_t)r * 2 + 1];
+    }
     const float f = A.Sf[r];
     int k = 0;
 #pragma unroll
@@ -225,9 +231,18 @@ __global__ __launch_bounds__(256) void k_lm_solve_step(mgs_lm_step_args A) {
       H[i][j] = v; H[j][i] = v;
       k++;
     }
+  float lambda = A.lambda;
+  if (A.lm_state) {      // trust-region rule on the device (slam_frontend.py:536-545)
+    lambda = A.lm_state[0];
+    const float loss = A.loss[0];
+    if (A.lm_state[2] != 0.f)
+      lambda = loss < A.lm_state[1] ? fmaxf(lambda / A.decrease_factor, A.min_lambda)
+                                    : fminf(lambda * A.increase_factor, A.max_lambda);
+    A.lm_state[0] = lambda; A.lm_state[1] = loss; A.lm_state[2] = 1.f;
+  }
   for (int i = 0; i < 8; i++) {
     g[i] = -(s_red[0][36 + i] + s_red[1][36 + i] + s_red[2][36 + i] + s_red[3][36 + i]);
-    H[i][i] += (double)A.lambda;
+    H[i][i] += (double)lambda;
   }
   // Cholesky H = L L^T (lambda > 0 makes H positive definite)
   double L[8][8];
@@ -249,6 +264,11 @@ __global__ __launch_bounds__(256) void k_lm_solve_step(mgs_lm_step_args A) {
     x[i] = sum / L[i][i];
   }
   for (int i = 0; i < 8; i++) A.x_out[i] = (float)x[i];
+  if (A.lm_state) {
+    double n2 = 0.0;
+    for (int i = 0; i < 8; i++) n2 += x[i] * x[i];
+    A.lm_state[3] = sqrt(n2) < (double)A.converged_threshold ? 1.f : 0.f;
+  }
   if (A.T) {
     const float rho[3] = {(float)x[0], (float)x[1], (float)x[2]};
     const float th[3] = {(float)x[3], (float)x[4], (float)x[5]};
@@ -357,6 +377,92 @@ __global__ __launch_bounds__(kLossBlock) void k_map_loss_bwd_finish(mgs_mapping_
   }
 }
 
+
+// ---------------------------------------------------------------------------------
+// Keyed pseudo-random permutation of [0, m): invertible rounds (add, odd multiply, xor-shift)
+// on `bits` = ceil(log2 m) bits, cycle-walked into range.  Every round is a bijection of
+// [0, 2^bits), so the composition is one, and walking a point of [0, m) along its cycle until
+// it lands in [0, m) again yields a bijection of [0, m).
+__device__ __forceinline__ unsigned int perm_round(unsigned int x, unsigned int mask, int bits,
+                                                   unsigned int k0, unsigned int k1) {
+  const int h = bits > 2 ? bits / 2 : 1;
+  x = (x + k0) & mask;
+  x = (x * 0x9E3779B1u) & mask;
+  x ^= x >> h;
+  x = (x * 0x85EBCA6Bu) & mask;
+  x = (x + k1) & mask;
+  x ^= x >> (h > 1 ? h - 1 : 1);
+  x = (x * 0xC2B2AE35u) & mask;
+  x ^= x >> h;
+  return x;
+}
+
+__device__ __forceinline__ unsigned int hash32(unsigned int x) {
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x;
+}
+
+__global__ __launch_bounds__(256) void k_sketch_assign(long long m, int chunk, int d, int bits,
+                                                       unsigned int k0, unsigned int k1, unsigned int k2,
+                                                       int* bucket, float* weights) {
+  const unsigned int mask = bits >= 32 ? 0xFFFFFFFFu : ((1u << bits) - 1u);
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < m; p += (long long)gridDim.x * 256) {
+    unsigned int x = (unsigned int)p;
+    do { x = perm_round(x, mask, bits, k0, k1); } while ((long long)x >= m);
+    const long long used = (long long)chunk * d;
+    bucket[p] = (long long)x < used ? (int)(x / (unsigned int)chunk) : -1;
+    weights[p] = (hash32((unsigned int)p ^ k2) & 0x10000u) ? 1.f : -1.f;
+  }
+}
+
+constexpr int kSketchBlocks = 128;
+
+__global__ __launch_bounds__(kLossBlock) void k_sketch_residual(mgs_sketch_residual_args A) {
+  extern __shared__ float s_acc[];   // [d][3]: Sf, d/da, d/db
+  __shared__ float s_red[kLossBlock / 64];
+  const int d = A.stack_dim * A.sketch_dim;
+  for (int i = threadIdx.x; i < 3 * d; i += kLossBlock) s_acc[i] = 0.f;
+  __syncthreads();
+  const float a = A.exposure_a[0];
+  const float gain = fabsf(a) + A.exposure_eps, bias = A.exposure_b[0];
+  const float sg = a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f);
+  const size_t HW = (size_t)A.num_pixels;
+  const float scale = (float)d / (float)A.num_pixels;      // 1 / (m / (stack * sketch))
+  float l1 = 0.f;
+  for (size_t p = (size_t)blockIdx.x * kLossBlock + threadIdx.x; p < HW; p += (size_t)gridDim.x * kLossBlock) {
+    const float om = A.opacity[p] * (A.mask ? A.mask[p] : 1.f);
+    const float w = A.weights[p] * scale;
+    float hs = 0.f, da = 0.f, db = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float im = A.image[c * HW + p];
+      const float r = om * (gain * im + bias - A.gt[c * HW + p]);
+      l1 += fabsf(r);
+      float dh;
+      hs += huber(r, A.huber_delta, dh);
+      const float g = w * dh * om;              // d weighted / d (gain * image + bias)
+      A.grad_image[c * HW + p] = g * gain;
+      da += g * im;
+      db += g;
+    }
+    const int b = A.bucket[p];
+    if (b >= 0 && b < d) {
+      atomicAdd(&s_acc[3 * b], w * hs);
+      atomicAdd(&s_acc[3 * b + 1], da * sg);
+      atomicAdd(&s_acc[3 * b + 2], db);
+    }
+  }
+  const float t = block_sum(l1, s_red);
+  if (threadIdx.x == 0) atomicAdd(A.l1, t);
+  __syncthreads();
+  for (int i = threadIdx.x; i < d; i += kLossBlock) {
+    const float f = s_acc[3 * i], x = s_acc[3 * i + 1], y = s_acc[3 * i + 2];
+    if (f != 0.f) atomicAdd(&A.Sf[i], f);
+    if (x != 0.f) atomicAdd(&A.sj_exposure[2 * i], x);
+    if (y != 0.f) atomicAdd(&A.sj_exposure[2 * i + 1], y);
+  }
+}
+
 static int loss_blocks(int64_t hw) {
   const int64_t b = (hw + kLossBlock - 1) / kLossBlock;
   return (int)(b < kLossBlocks ? (b < 1 ? 1 : b) : kLossBlocks);
@@ -409,8 +515,45 @@ int32_t mgs_mapping_loss_backward(const mgs_mapping_loss_args* a, void* stream) 
 }
 
 int32_t mgs_lm_solve_step(const mgs_lm_step_args* a, void* stream) {
-  if (!a || !a->SJ || !a->Sf || !a->x_out || a->rows < 1 || !(a->lambda > 0.f)) return MGS_ERR_BAD_ARGUMENT;
+  if (!a || !a->Sf || !a->x_out || a->rows < 1) return MGS_ERR_BAD_ARGUMENT;
+  if (!a->SJ && (!a->sj_tau || !a->sj_exposure)) return MGS_ERR_BAD_ARGUMENT;
+  if (a->lm_state ? (!a->loss || !(a->increase_factor > 0.f) || !(a->decrease_factor > 0.f)) : !(a->lambda > 0.f))
+    return MGS_ERR_BAD_ARGUMENT;
   launch("lm_solve_step", k_lm_solve_step, dim3(1), dim3(256), (hipStream_t)stream, *a);
+  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+}
+
+int32_t mgs_sketch_assign(int64_t num_pixels, int32_t stack_dim, int32_t sketch_dim, uint64_t key,
+                          int32_t* bucket, float* weights, void* stream) {
+  if (num_pixels < 1 || num_pixels > 0x7fffffffLL || stack_dim < 1 || sketch_dim < 1 || !bucket || !weights)
+    return MGS_ERR_BAD_ARGUMENT;
+  const int d = stack_dim * sketch_dim;
+  const int chunk = (int)(num_pixels / d);
+  if (chunk < 1) return MGS_ERR_BAD_ARGUMENT;
+  int bits = 1;
+  while ((1LL << bits) < num_pixels) bits++;
+  // three 32-bit round keys from the 64-bit key (splitmix64)
+  uint64_t z = key + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+  const unsigned int k0 = (unsigned int)z, k1 = (unsigned int)(z >> 32);
+  z = (z + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull; z ^= z >> 29;
+  const unsigned int k2 = (unsigned int)(z >> 16);
+  const int nb = loss_blocks(num_pixels);
+  launch("sketch_assign", k_sketch_assign, dim3(nb), dim3(256), (hipStream_t)stream, (long long)num_pixels, chunk,
+         d, bits, k0, k1, k2, bucket, weights);
+  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+}
+
+int32_t mgs_sketch_residual(const mgs_sketch_residual_args* a, void* stream) {
+  if (!a || !a->image || !a->opacity || !a->gt || !a->exposure_a || !a->exposure_b || !a->bucket ||
+      !a->weights || !a->grad_image || !a->Sf || !a->sj_exposure || !a->l1 || a->num_pixels < 1 ||
+      a->stack_dim < 1 || a->sketch_dim < 1)
+    return MGS_ERR_BAD_ARGUMENT;
+  const size_t smem = sizeof(float) * 3 * (size_t)a->stack_dim * a->sketch_dim;
+  if (smem > 48 * 1024) return MGS_ERR_UNSUPPORTED;
+  const int64_t want = (a->num_pixels + kLossBlock - 1) / kLossBlock;
+  const int nb = (int)(want < kSketchBlocks ? want : kSketchBlocks);
+  launch_smem("sketch_residual", k_sketch_residual, dim3(nb), dim3(kLossBlock), smem, (hipStream_t)stream, *a);
   return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
 }
 

@@ -162,17 +162,40 @@ def gen_forward_sketch_args(height, width, repeat_dim, stack_dim, sketch_dim, de
             "chunk_size": chunk, "rand_weights": weights}
 
 
+def sketch_args_from_buckets(bucket: torch.Tensor, weights: torch.Tensor, height, width, stack_dim,
+                             sketch_dim):
+    """forward_sketch_args (repeat_dim = 1) for a given bucket partition: `bucket` [H*W] =
+    stack * sketch_dim + k or -1 and `weights` [H*W] = +-1, as mgs_sketch_assign produces them."""
+    dev = bucket.device
+    m, d = height * width, stack_dim * sketch_dim
+    chunk = m // d
+    b = bucket.long()
+    idx = torch.full((stack_dim, m), -1, dtype=torch.int32, device=dev)
+    p = torch.nonzero(b >= 0).squeeze(1)
+    idx[b[p] // sketch_dim, p] = (b[p] % sketch_dim).to(torch.int32)
+    order = p[torch.argsort(b[p], stable=True)]                   # pixels grouped by bucket
+    rows = (order // width).view(1, stack_dim, sketch_dim, chunk).to(torch.int32)
+    cols = (order % width).view(1, stack_dim, sketch_dim, chunk).to(torch.int32)
+    return {"sketch_mode": 1, "repeat_dim": 1, "stack_dim": stack_dim, "sketch_dim": sketch_dim,
+            "sketch_indices": idx.reshape(1, stack_dim, height, width),
+            "rand_indices": (rows, cols), "rand_indices_row": rows, "rand_indices_col": cols,
+            "sketch_dtau": torch.empty(stack_dim, sketch_dim, 6, device=dev, requires_grad=True),
+            "sketch_dexposure": torch.empty(stack_dim, sketch_dim, 2, device=dev, requires_grad=True),
+            "chunk_size": chunk, "rand_weights": weights.reshape(1, height, width).float()}
+
+
 def tracking_step_second_order(viewpoint, gaussians, background, lambda_, repeat_dim=1,
                                stack_dim=16, sketch_dim=64, pipe=Pipe, config=DEFAULT_CONFIG,
-                               generator=None, fused_solve=False):
+                               generator=None, fused_solve=False, fsa=None):
     """One sketched Levenberg-Marquardt iteration (slam_frontend.py:484-710): sketched
     render, bucket-summed residual Sf, `repeat_dim` backward passes harvesting the sketched
     Jacobian SJ[(repeat*stack*sketch), 8], damped least squares, left-multiplicative pose
     step and exposure step."""
     H, W = viewpoint.image_height, viewpoint.image_width
     m, dper = H * W, stack_dim * sketch_dim
-    fsa = gen_forward_sketch_args(H, W, repeat_dim, stack_dim, sketch_dim, viewpoint.device,
-                                  generator)
+    if fsa is None:
+        fsa = gen_forward_sketch_args(H, W, repeat_dim, stack_dim, sketch_dim, viewpoint.device,
+                                      generator)
     render_pkg = render(viewpoint, gaussians, pipe, background, forward_sketch_args=fsa)
     res = get_loss_tracking_per_pixel(config, render_pkg["render"], render_pkg["depth"],
                                       render_pkg["opacity"], viewpoint, forward_sketch_args=fsa)

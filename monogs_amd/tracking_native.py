@@ -126,6 +126,52 @@ class NativeTracker:
         a.fwd.bins, a.bwd = self.bins.data_ptr(), self.bwd.data_ptr()
         self.capacity = cap
 
+    # ---- second order (sketched Levenberg-Marquardt, slam_frontend.py:455-710) ----------
+    def enable_second_order(self, stack_dim=16, sketch_dim=64, initial_lambda=1e-3, max_lambda=1e7,
+                            min_lambda=1e-6, increase_factor=5.0, decrease_factor=5.0,
+                            converged_threshold=1e-5, seed=0):
+        """Allocate the sketch scratch; defaults are configs/mono/tum/base_config.yaml:255-268."""
+        dev, HW = self.dev, self.H * self.W
+        d = stack_dim * sketch_dim
+        so = _cabi.TrackingSOArgs()
+        C.memmove(C.byref(so.base), C.byref(self.args), C.sizeof(_cabi.TrackingIterArgs))
+        sizes = _cabi.workspace_sizes(so.base.fwd.shape)
+        self.so_bucket = torch.empty(HW, dtype=torch.int32, device=dev)
+        self.so_weights = torch.empty(HW, device=dev)
+        self.so_accum = torch.zeros(9 * d + 4, device=dev)
+        self.so_sketch_ws = torch.empty(int(sizes.sketch_bytes), dtype=torch.uint8, device=dev)
+        self.lm_state = torch.tensor([initial_lambda, 0.0, 0.0, 0.0], device=dev)
+        self.so_x = torch.zeros(8, device=dev)
+        so.stack_dim, so.sketch_dim = stack_dim, sketch_dim
+        so.bucket, so.weights = self.so_bucket.data_ptr(), self.so_weights.data_ptr()
+        so.accum, so.sketch_ws = self.so_accum.data_ptr(), self.so_sketch_ws.data_ptr()
+        so.lm.lm_state, so.lm.x_out = self.lm_state.data_ptr(), self.so_x.data_ptr()
+        so.lm.increase_factor, so.lm.decrease_factor = increase_factor, decrease_factor
+        so.lm.min_lambda, so.lm.max_lambda = min_lambda, max_lambda
+        so.lm.converged_threshold = converged_threshold
+        self.so_args, self.so_d, self.so_seed, self.so_t = so, d, int(seed), 0
+
+    def step_second_order(self):
+        """Enqueue one sketched LM iteration: fresh random bucket partition, forward, sketched
+        residual, sketch-mode backward, damped solve and pose / exposure step, all on the
+        device.  Returns lm_state = [lambda, ||residual||_1, 1, converged] (device tensor)."""
+        so = self.so_args
+        # pointers that _alloc_bins may have replaced since enable_second_order
+        so.base.fwd.bins, so.base.bwd = self.args.fwd.bins, self.args.bwd
+        so.base.fwd.shape.pair_capacity = self.args.fwd.shape.pair_capacity
+        self.so_t += 1
+        so.key = (self.so_seed * 0x9E3779B97F4A7C15 + self.so_t) & 0xFFFFFFFFFFFFFFFF
+        _cabi.check(_cabi.lib().mgs_tracking_iteration_second_order(C.byref(so), self._stream()),
+                    "mgs_tracking_iteration_second_order")
+        return self.lm_state
+
+    @property
+    def sketch(self):
+        """(Sf [d], SJ [d, 8]) of the last second-order iteration (views / a small cat)."""
+        d = self.so_d
+        a = self.so_accum
+        return a[:d], torch.cat((a[3 * d:9 * d].view(d, 6), a[d:3 * d].view(d, 2)), dim=1)
+
     def step(self):
         """Enqueue one iteration; returns the device convergence flag (int32[1])."""
         self.t += 1

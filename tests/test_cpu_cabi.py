@@ -34,7 +34,11 @@ def test_struct_layout_matches_header(built):
     assert C.sizeof(_cabi.RasterShape) == 36
     assert C.sizeof(_cabi.ForwardArgs) == 40 + 19 * 8
     assert C.sizeof(_cabi.WorkspaceSizes) == 12 * 8
-    assert C.sizeof(_cabi.BackwardArgs) == C.sizeof(_cabi.ForwardArgs) + 11 * 8 + 16 + 3 * 8
+    # every ctypes mirror against the compiler's sizeof (mgs_struct_size)
+    lib = _cabi.lib()
+    for i, cls in enumerate(_cabi.struct_mirrors()):
+        assert C.sizeof(cls) == lib.mgs_struct_size(i), cls.__name__
+    assert lib.mgs_struct_size(len(_cabi.struct_mirrors())) == -1
 
 
 def test_workspace_query_and_status_strings(built):

@@ -1065,3 +1065,83 @@ def test_gradient_bucket_pack_kernel_matches_torch(built):
     assert torch.allclose(b.flat, want, rtol=1e-6, atol=0)
     assert torch.equal(rad, radii) and torch.equal(denom, (radii > 0).float())
     assert params[4].grad.data_ptr() == b.flat[sum(p.numel() for p in params[:4]):].data_ptr()
+
+
+def test_sketch_assign_is_a_random_partition_into_equal_buckets(built):
+    """mgs_sketch_assign: every bucket gets exactly chunk = HW // (stack*sketch) pixels (the
+    structure of slam_frontend.py:269-338), leftovers are -1, weights are +-1 and roughly
+    balanced, and a different key gives a different partition."""
+    import ctypes as C
+    from monogs_amd import _cabi
+    dev = _dev()
+    lib = _cabi.lib()
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for (HW, stack, sketch) in ((640 * 480, 16, 64), (160 * 120 + 7, 4, 8), (33, 2, 3)):
+        d, chunk = stack * sketch, HW // (stack * sketch)
+        prev = None
+        for key in (1, 2):
+            bucket = torch.empty(HW, dtype=torch.int32, device=dev)
+            w = torch.empty(HW, device=dev)
+            _cabi.check(lib.mgs_sketch_assign(HW, stack, sketch, key, bucket.data_ptr(), w.data_ptr(), stream), "assign")
+            b = bucket.cpu().long()
+            assert int((b < 0).sum()) == HW - chunk * d and b.max() < d
+            counts = torch.bincount(b[b >= 0], minlength=d)
+            assert bool((counts == chunk).all())
+            assert bool((w.abs() == 1).all())
+            if HW > 1000:
+                assert abs(w.mean().item()) < 0.05
+                # pixels of a bucket are spread over the image, not contiguous runs
+                px = torch.nonzero(b == 0).squeeze(1).float()
+                assert px.std().item() > 0.15 * HW
+            if prev is not None and HW > 1000:
+                assert (prev != b).float().mean().item() > 0.9
+            prev = b
+
+
+def test_native_second_order_iteration_matches_python_formulation(built):
+    """mgs_tracking_iteration_second_order against tracking_step_second_order (the reference-
+    shaped autograd formulation) on the SAME bucket partition and weights: Sf, the sketched
+    Jacobian SJ [d, 8], the LM step and the updated pose / exposure."""
+    from monogs_amd.gaussian_renderer import render
+    from monogs_amd.pose import SE3_exp
+    from monogs_amd.slam_loops import Pipe, sketch_args_from_buckets, tracking_step_second_order
+    from monogs_amd.tracking_native import NativeTracker
+    sc, gauss, view, dev = _loop_fixture()
+    bg = torch.zeros(3, device=dev)
+    with torch.no_grad():
+        target = render(view(1, torch.eye(4)), gauss, Pipe, bg)["render"].clone()
+    T0 = SE3_exp(torch.tensor([0.02, -0.015, 0.01, 0.004, -0.006, 0.003]))
+    va, vb = view(2, T0), view(3, T0)
+    for v in (va, vb):
+        v.original_image = target
+        v.rgb_pixel_mask_mapping = (target.sum(0) > 0.01).view(1, *target.shape[1:])
+        with torch.no_grad():
+            v.exposure_a.fill_(0.97)
+            v.exposure_b.fill_(0.01)
+    H, W = va.image_height, va.image_width
+    stack, sketch, lam = 4, 16, 1e-3
+    trk = NativeTracker(vb, gauss, bg)
+    trk.enable_second_order(stack_dim=stack, sketch_dim=sketch, initial_lambda=lam, seed=5)
+    state = trk.step_second_order()
+    torch.cuda.synchronize()
+    Sf_n, SJ_n = trk.sketch
+    fsa = sketch_args_from_buckets(trk.so_bucket, trk.so_weights, H, W, stack, sketch)
+    l1, x, SJ, Sf = tracking_step_second_order(va, gauss, bg, lambda_=lam, repeat_dim=1, stack_dim=stack,
+                                               sketch_dim=sketch, fused_solve=True, fsa=fsa)
+    assert rel_err(Sf_n, Sf) < 1e-4
+    assert rel_err(SJ_n[:, 6:], SJ[:, 6:]) < 1e-4            # exposure columns
+    assert rel_err(SJ_n[:, :6], SJ[:, :6]) < 2e-3            # pose columns (through the rasteriser)
+    assert rel_err(trk.so_x, x) < 5e-3
+    assert torch.allclose(va.T, vb.T, atol=1e-4)
+    assert torch.allclose(va.exposure_a, vb.exposure_a, atol=1e-4)
+    st = state.cpu()
+    assert abs(st[0].item() - lam) < 1e-9 and st[2].item() == 1.0
+    # trust-region rule on the device: the loss decreased after a good step -> lambda / 5
+    before = st[1].item()
+    st2 = trk.step_second_order().cpu()
+    assert st2[1].item() < before and abs(st2[0].item() - lam / 5.0) < 1e-9
+    # the pose keeps improving over a few iterations
+    for _ in range(6):
+        trk.step_second_order()
+    assert trk.check_capacity()
+    assert (vb.T.cpu() - torch.eye(4)).abs().max().item() < 0.5 * (T0 - torch.eye(4)).abs().max().item()
