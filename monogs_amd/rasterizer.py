@@ -160,18 +160,27 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         bins = None
         retried = False
+        prepared = None
+        needs_grad = any(ctx.needs_input_grad[:10])
+        saved_small = (means3D_c, sh_c, col_c, op_c, sc_c, rot_c, cov_c, view, proj, praw, campos, bg, geom)
         if hint:
             bins = run_blend(int(hint))      # optimistic: overlaps the host wait below
+            if needs_grad:                   # ... and so does the preparation of the backward
+                prepared = _RasterizeGaussians._prepare_backward(
+                    saved_small + (bins,), st, (N, W, H, int(st.sh_degree), K, int(hint)),
+                    (int(sketch_mode), int(sketch_dim), int(stack_dim)))
         ev.synchronize()
         D = int(host_cnt.item())
         if bins is None or D > shape.pair_capacity:
             retried = bins is not None
+            prepared = None                  # sized for the old capacity
             bins = run_blend(_round_cap(D))
         # high-water mark with slow decay, so one unusually heavy view does not pin memory forever
         _capacity_hint[dev.index] = max(_round_cap(D), int(shape.pair_capacity * 0.97) // 1024 * 1024)
         last_stats.update(pairs=D, capacity=int(shape.pair_capacity), retried=retried, N=N)
 
         ctx.raster_settings = st
+        ctx.prepared = prepared
         ctx.shape_tuple = (N, W, H, int(st.sh_degree), K, int(shape.pair_capacity))
         ctx.sketch = (int(sketch_mode), int(sketch_dim), int(stack_dim))
         ctx.sketch_indices = sketch_indices
@@ -188,29 +197,31 @@ class _RasterizeGaussians(torch.autograd.Function):
         return color, radii, depth, opacity, n_touched
 
     @staticmethod
-    def backward(ctx, grad_color, grad_radii, grad_depth, grad_opacity, grad_n_touched):
-        (means3D, sh, col, op, sc, rot, cov, view, proj, praw, campos, bg, geom,
-         bins) = ctx.saved_tensors
-        st = ctx.raster_settings
+    def _prepare_backward(saved, st, shape_tuple, sketch):
+        """Everything of the backward that does not depend on the incoming gradients: output /
+        scratch allocations and the argument block.  Called from forward() while the host is
+        waiting for the GPU anyway, so that backward() itself is a handful of pointer stores and
+        one library call (the host work between the pair-count wait and the backward launch is
+        what decides whether the GPU runs dry on a slow host)."""
+        (means3D, sh, col, op, sc, rot, cov, view, proj, praw, campos, bg, geom, bins) = saved
         dev = means3D.device
-        lib = _cabi.lib()
-        N, W, H, deg, K, cap = ctx.shape_tuple
+        N, W, H, deg, K, cap = shape_tuple
         shape = _cabi.RasterShape(N, W, H, deg, K, cap, float(st.tanfovx), float(st.tanfovy),
                                   float(st.scale_modifier))
         sizes = _sizes(shape)
-        bwd_ws = torch.empty(int(sizes.bwd_bytes), dtype=torch.uint8, device=dev)
-        g_means3D = torch.empty(N, 3, dtype=torch.float32, device=dev)
-        g_means2D = torch.empty(N, 3, dtype=torch.float32, device=dev)
-        g_colors = (torch.empty(N, K, 3, dtype=torch.float32, device=dev) if sh is not None
-                    else torch.empty(N, 3, dtype=torch.float32, device=dev))
-        g_op = torch.empty(N, dtype=torch.float32, device=dev)
-        g_sc = torch.empty(N, 3, dtype=torch.float32, device=dev) if sc is not None else None
-        g_rot = torch.empty(N, 4, dtype=torch.float32, device=dev) if rot is not None else None
-        g_cov = torch.empty(N, 6, dtype=torch.float32, device=dev) if cov is not None else None
-        g_tau = torch.empty(6, dtype=torch.float32, device=dev)
-        gc = _f32c(grad_color) if grad_color is not None else torch.zeros(3, H, W, device=dev)
-        gd = _f32c(grad_depth) if grad_depth is not None else None
-
+        out = {
+            "bwd_ws": torch.empty(int(sizes.bwd_bytes), dtype=torch.uint8, device=dev),
+            "g_means3D": torch.empty(N, 3, dtype=torch.float32, device=dev),
+            "g_means2D": torch.empty(N, 3, dtype=torch.float32, device=dev),
+            "g_colors": (torch.empty(N, K, 3, dtype=torch.float32, device=dev) if sh is not None
+                         else torch.empty(N, 3, dtype=torch.float32, device=dev)),
+            "g_op": torch.empty(N, dtype=torch.float32, device=dev),
+            "g_sc": torch.empty(N, 3, dtype=torch.float32, device=dev) if sc is not None else None,
+            "g_rot": torch.empty(N, 4, dtype=torch.float32, device=dev) if rot is not None else None,
+            "g_cov": torch.empty(N, 6, dtype=torch.float32, device=dev) if cov is not None else None,
+            "g_tau": torch.empty(6, dtype=torch.float32, device=dev),
+            "sizes": sizes,
+        }
         b = _cabi.BackwardArgs()
         f = b.fwd
         f.shape = shape
@@ -220,11 +231,31 @@ class _RasterizeGaussians(torch.autograd.Function):
         f.viewmatrix, f.projmatrix, f.projmatrix_raw = _ptr(view), _ptr(proj), _ptr(praw)
         f.campos, f.bg = _ptr(campos), _ptr(bg)
         f.geom, f.bins = _ptr(geom), _ptr(bins)
-        b.grad_color, b.grad_depth, b.bwd = _ptr(gc), _ptr(gd), _ptr(bwd_ws)
-        b.grad_means3D, b.grad_means2D = _ptr(g_means3D), _ptr(g_means2D)
-        b.grad_colors, b.grad_opacities = _ptr(g_colors), _ptr(g_op)
-        b.grad_scales, b.grad_rotations, b.grad_cov3D = _ptr(g_sc), _ptr(g_rot), _ptr(g_cov)
-        b.grad_tau = _ptr(g_tau)
+        b.bwd = _ptr(out["bwd_ws"])
+        b.grad_means3D, b.grad_means2D = _ptr(out["g_means3D"]), _ptr(out["g_means2D"])
+        b.grad_colors, b.grad_opacities = _ptr(out["g_colors"]), _ptr(out["g_op"])
+        b.grad_scales, b.grad_rotations, b.grad_cov3D = _ptr(out["g_sc"]), _ptr(out["g_rot"]), _ptr(out["g_cov"])
+        b.grad_tau = _ptr(out["g_tau"])
+        out["args"] = b
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth, grad_opacity, grad_n_touched):
+        saved = ctx.saved_tensors
+        means3D = saved[0]
+        st = ctx.raster_settings
+        dev = means3D.device
+        lib = _cabi.lib()
+        N, W, H, deg, K, cap = ctx.shape_tuple
+        # buffers prepared by forward() serve the first backward; a repeated backward
+        # (retain_graph, sketch repeats) must not overwrite gradients already handed out
+        pre, ctx.prepared = getattr(ctx, "prepared", None), None
+        if pre is None:
+            pre = _RasterizeGaussians._prepare_backward(saved, st, ctx.shape_tuple, ctx.sketch)
+        b = pre["args"]
+        gc = _f32c(grad_color) if grad_color is not None else torch.zeros(3, H, W, device=dev)
+        gd = _f32c(grad_depth) if grad_depth is not None else None
+        b.grad_color, b.grad_depth = _ptr(gc), _ptr(gd)
         sketch_mode, sketch_dim, stack_dim = ctx.sketch
         g_sketch = None
         keep = []
@@ -233,16 +264,17 @@ class _RasterizeGaussians(torch.autograd.Function):
             idx = idx_all[ctx.repeat_iter].contiguous()   # [stack,H,W] int32
             ctx.repeat_iter += 1
             g_sketch = torch.empty(stack_dim, sketch_dim, 6, dtype=torch.float32, device=dev)
-            sk_ws = torch.empty(int(sizes.sketch_bytes), dtype=torch.uint8, device=dev)
+            sk_ws = torch.empty(int(pre["sizes"].sketch_bytes), dtype=torch.uint8, device=dev)
             keep += [idx, sk_ws]
             b.sketch_mode, b.sketch_dim, b.stack_dim = sketch_mode, sketch_dim, stack_dim
             b.sketch_indices, b.grad_sketch_dtau, b.sketch_ws = _ptr(idx), _ptr(g_sketch), _ptr(sk_ws)
         _cabi.check(lib.mgs_raster_backward(C.byref(b), _stream_ptr(dev)), "mgs_raster_backward")
 
         has_sh, has_col, _, _, _ = ctx.has
-        return (g_means3D, g_means2D, g_colors if has_sh else None,
-                g_colors if has_col else None, g_op.reshape(ctx.op_shape), g_sc, g_rot, g_cov,
-                g_tau[3:], g_tau[:3], None, None, None, None, g_sketch, None)
+        g_colors, g_tau = pre["g_colors"], pre["g_tau"]
+        return (pre["g_means3D"], pre["g_means2D"], g_colors if has_sh else None,
+                g_colors if has_col else None, pre["g_op"].reshape(ctx.op_shape), pre["g_sc"], pre["g_rot"],
+                pre["g_cov"], g_tau[3:], g_tau[:3], None, None, None, None, g_sketch, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
