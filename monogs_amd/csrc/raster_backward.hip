@@ -152,12 +152,12 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr float kLog2eB = 1.4426950408889634f;
 
 template <bool SKETCH>
-__global__ __launch_bounds__(64, 6) void k_blend_bwd(KP P, KB B) {
+__global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
   static_assert(kSeg == 64, "one staged record per lane");
   __shared__ float4 s_r0[kSeg], s_r1[kSeg];
   __shared__ float2 s_r2[kSeg];
   __shared__ unsigned int s_mask[kSeg];
-  __shared__ float4 s_coef[SKETCH ? kSeg : 1][9];   // per splat: 6 tau components x 6 coefficients
+  __shared__ float4 s_coef[SKETCH ? kSeg : 1][9];   // per splat: 6 features x 6 tau components
   const int item = xcd_remap<kBwdChunk>(blockIdx.x), lane = threadIdx.x;
   if (item >= min(P.seg_offset[P.T], P.max_segs)) return;
   const int tile = P.seg_tile[item];
@@ -255,11 +255,12 @@ __global__ __launch_bounds__(64, 6) void k_blend_bwd(KP P, KB B) {
   }
   __syncthreads();
 
-  float J[SKETCH ? 4 : 1][6];   // sketch mode: per-pixel pose-Jacobian rows of this segment
+  // sketch mode: per-pixel pose-Jacobian rows of this segment, as pairs (tau 0,1) (2,3) (4,5)
+  v2f J2[SKETCH ? 4 : 1][3];
 #pragma unroll
   for (int q = 0; q < (SKETCH ? 4 : 1); q++)
 #pragma unroll
-    for (int t = 0; t < 6; t++) J[q][t] = 0.f;
+    for (int t = 0; t < 3; t++) J2[q][t] = v2f{0.f, 0.f};
   // reduce-scatter bookkeeping (wave_reduce.h): which of the ten sums this lane ends up with
   const unsigned long long b3mask = __ballot((lane & 8) != 0);
   const bool wextra = lane == 31 || lane == 63;
@@ -285,6 +286,7 @@ __global__ __launch_bounds__(64, 6) void k_blend_bwd(KP P, KB B) {
     const float2 bd2 = s_r2[j];
     const v2f mu = {u.x, u.y}, RG = {v.z, v.w}, BD = {bd2.x, bd2.y};
     const int idx = base + j;
+    const v2f* cf2 = reinterpret_cast<const v2f*>(&s_coef[SKETCH ? j : 0][0]);   // [feature][tau pair]
     // pixel sums of this splat: S1 | (Sx, Sy) | (Sxx, Sxy) | Syy | (Rr, Rg) | (Rb, Rd)
     float r0 = 0.f, r5 = 0.f;
     v2f R12 = {0.f, 0.f}, R34 = {0.f, 0.f}, R67 = {0.f, 0.f}, R89 = {0.f, 0.f};
@@ -318,14 +320,17 @@ __global__ __launch_bounds__(64, 6) void k_blend_bwd(KP P, KB B) {
       R67 = __builtin_elementwise_fma(ww, G01[q], R67);
       R89 = __builtin_elementwise_fma(ww, G2d[q], R89);
       if constexpr (SKETCH) {
-        // J_t += W (c0 dx + c1 dy + c2 dx^2 + c3 dx dy + c4 dy^2) + (w dL/dD) c5
-        const float Wx = Wxy.x, Wy = Wxy.y;
-        const float X3 = Wx * d.x, X4 = Wx * d.y, X5 = Wy * d.y, X6 = w * G2d[q].y;
-        const float* cf = reinterpret_cast<const float*>(&s_coef[j][0]);
+        // J_t += W (c0 dx + c1 dy + c2 dx^2 + c3 dx dy + c4 dy^2) + (w dL/dD) c5 for the six tau
+        // components: the splat's 36 coefficients are staged in LDS in feature-major order, so two
+        // tau components share one packed FMA (18 instead of 36 per quadrant)
+        const float X[6] = {Wxy.x, Wxy.y, Wxy.x * d.x, Wxy.x * d.y, Wxy.y * d.y, w * G2d[q].y};
 #pragma unroll
-        for (int t = 0; t < 6; t++)
-          J[q][t] += cf[6 * t] * Wx + cf[6 * t + 1] * Wy + cf[6 * t + 2] * X3 + cf[6 * t + 3] * X4 +
-                     cf[6 * t + 4] * X5 + cf[6 * t + 5] * X6;
+        for (int i = 0; i < 6; i++) {
+          const v2f xi = {X[i], X[i]};
+#pragma unroll
+          for (int t = 0; t < 3; t++)
+            J2[q][t] = __builtin_elementwise_fma(cf2[3 * i + t], xi, J2[q][t]);
+        }
       }
     }
     if (any) {
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(64, 6) void k_blend_bwd(KP P, KB B) {
       if (px < P.W && py < P.H) {
         const size_t pix = (size_t)py * P.W + px;
 #pragma unroll
-        for (int t = 0; t < 6; t++) atomicAdd(&B.pix_jac[(size_t)t * HW + pix], J[q][t]);
+        for (int t = 0; t < 6; t++) atomicAdd(&B.pix_jac[(size_t)t * HW + pix], (t & 1) ? J2[q][t >> 1].y : J2[q][t >> 1].x);
       }
     }
   }
@@ -404,13 +409,13 @@ __global__ __launch_bounds__(kPreBlock) void k_sketch_prep(KP P, KB B) {
   }
   const float A = r1.x, Bc = r1.y, Cc = r1.z;
 #pragma unroll
-  for (int t = 0; t < 6; t++) {
-    out[6 * t + 0] = -(A * M[0][t] + Bc * M[1][t]);
-    out[6 * t + 1] = -(Bc * M[0][t] + Cc * M[1][t]);
-    out[6 * t + 2] = -0.5f * M[2][t];
-    out[6 * t + 3] = -M[3][t];
-    out[6 * t + 4] = -0.5f * M[4][t];
-    out[6 * t + 5] = M[5][t];
+  for (int t = 0; t < 6; t++) {      // feature-major: out[6 * feature + tau component]
+    out[6 * 0 + t] = -(A * M[0][t] + Bc * M[1][t]);
+    out[6 * 1 + t] = -(Bc * M[0][t] + Cc * M[1][t]);
+    out[6 * 2 + t] = -0.5f * M[2][t];
+    out[6 * 3 + t] = -M[3][t];
+    out[6 * 4 + t] = -0.5f * M[4][t];
+    out[6 * 5 + t] = M[5][t];
   }
 }
 
