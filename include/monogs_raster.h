@@ -95,6 +95,10 @@ typedef struct mgs_forward_args {
   float* out_opacity;  /* [1,H,W] */
   int32_t* radii;      /* [N] */
   int32_t* n_touched;  /* [N] */
+  /* optional: stage 1 also stores the pair count D here.  May be pinned HOST memory
+   * (device-accessible): the caller then learns D from an event recorded after stage 1
+   * without a device-to-host copy in the stream. */
+  int32_t* pair_count_out;
 } mgs_forward_args;
 
 typedef struct mgs_backward_args {

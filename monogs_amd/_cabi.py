@@ -47,7 +47,7 @@ class ForwardArgs(C.Structure):
     _fields_ = [("shape", RasterShape)] + [(n, _fp) for n in (
         "means3D", "scales", "rotations", "cov3D_precomp", "opacities", "shs", "colors_precomp",
         "viewmatrix", "projmatrix", "projmatrix_raw", "campos", "bg", "geom", "bins",
-        "out_color", "out_depth", "out_opacity", "radii", "n_touched")]
+        "out_color", "out_depth", "out_opacity", "radii", "n_touched", "pair_count_out")]
 
 
 class BackwardArgs(C.Structure):

@@ -337,6 +337,7 @@ __device__ __forceinline__ void tile_scan_body(const KP& P, int nbin, int* s_sum
     P.seg_offset[P.T] = s_seg[1023];
     P.counters[0] = s_sum[1023];
     P.counters[1] = s_seg[1023];
+    if (P.d_out) __hip_atomic_store(P.d_out, s_sum[1023], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 

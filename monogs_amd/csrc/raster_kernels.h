@@ -40,6 +40,7 @@ struct KP {
   // forward outputs
   float *out_color, *out_depth, *out_opacity;
   int *radii, *n_touched;
+  int* d_out;              // optional extra destination of D (may be pinned host memory)
 };
 
 struct KB {   // backward extras

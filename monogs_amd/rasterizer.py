@@ -142,11 +142,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         a.radii, a.n_touched = _ptr(radii), _ptr(n_touched)
         stream = _stream_ptr(dev)
 
-        _cabi.check(lib.mgs_raster_forward_project(C.byref(a), stream), "mgs_raster_forward_project")
-        off = int(sizes.off_counters)
-        counter = geom[off:off + 4].view(torch.int32)
+        # the pair count D lands directly in a pinned host slot (no copy kernel in the stream)
         host_cnt, ev = _host_counter(dev.index)
-        host_cnt.copy_(counter, non_blocking=True)
+        a.pair_count_out = host_cnt.data_ptr()
+        _cabi.check(lib.mgs_raster_forward_project(C.byref(a), stream), "mgs_raster_forward_project")
         ev.record(torch.cuda.current_stream(dev))
 
         def run_blend(cap):
