@@ -187,6 +187,18 @@ typedef struct mgs_pose_adam_args {
   float lr_rot, lr_trans, lr_a, lr_b;
   float beta1, beta2, eps;
   float converged_threshold;
+  /* optional fusions (NULL / 0 = off), used by mgs_tracking_iteration to save launches:
+   * the block partials of dL/dtau ([n,6], instead of grad_trans / grad_rot) and of the exposure
+   * gradients ([2,n]: d/da then d/db, instead of grad_a / grad_b) are summed here in index
+   * order, and the camera matrices of the UPDATED pose are written (viewmatrix = T^T,
+   * projmatrix = viewmatrix @ projection). */
+  const float* tau_partials;
+  int32_t num_tau_partials;
+  const float* exposure_partials;
+  int32_t num_exposure_partials;
+  const float* projection;
+  float* viewmatrix_out;
+  float* projmatrix_out;
 } mgs_pose_adam_args;
 
 int32_t mgs_pose_adam_step(const mgs_pose_adam_args* args, void* stream);
@@ -255,7 +267,8 @@ int32_t mgs_lm_solve_step(const mgs_lm_step_args* args, void* stream);
 /* Monocular tracking objective (utils/slam_utils.py:188-205, :58-75; norm at
  * utils/slam_frontend.py:596-598):
  *   loss = || Huber_delta( opacity * mask * ((|a| + eps) * image + b - gt) ) ||_2
- * huber_delta <= 0 disables Huber.  `partial` holds mgs_tracking_loss_partial_count floats,
+ * huber_delta <= 0 disables Huber.  `partial` holds mgs_tracking_loss_partial_count floats
+ * (three per reduction block: forward sums, then the two exposure-gradient sums),
  * `scalars` 2 floats ([0] = loss, [1] = 1/loss) written by forward and read by backward. */
 typedef struct mgs_tracking_loss_args {
   const float* image;          /* [3,H,W] */
@@ -294,7 +307,8 @@ int32_t mgs_camera_from_pose(const float* T, const float* projection, float* vie
  * no host round trip (the Python loop body costs ~1 ms of host time per iteration):
  *   camera matrices from T -> rasteriser forward (project + blend at the caller's fixed
  *   pair capacity) -> tracking objective (mgs_tracking_loss_*) -> pose-only rasteriser
- *   backward -> Adam on (rot, trans, exposure a, b) + update_pose (mgs_pose_adam_step).
+ *   backward -> Adam on (rot, trans, exposure a, b) + update_pose (mgs_pose_adam_step), with
+ *   the small reduction kernels folded into their consumers (14 launches).
  * fwd.viewmatrix / fwd.projmatrix / fwd.campos must point at caller-owned device buffers
  * (16/16/>=3 floats; campos may alias viewmatrix) that this call REWRITES from T;
  * fwd.projmatrix_raw is the projection.  The forward is complete iff counters[0] (pair
@@ -309,6 +323,8 @@ typedef struct mgs_tracking_iter_args {
   const float* one;           /* [1] = 1.0f (dL/dloss) */
   mgs_tracking_loss_args loss;   /* image/opacity/grad_* fields are filled in by the call */
   mgs_pose_adam_args adam;       /* grad_* fields are filled in by the call; T must be set */
+  int32_t camera_matrices_valid; /* != 0: fwd.viewmatrix / projmatrix already match T (every
+                                    mgs_tracking_iteration leaves them so): skip that launch */
 } mgs_tracking_iter_args;
 
 int32_t mgs_tracking_iteration(const mgs_tracking_iter_args* args, void* stream);

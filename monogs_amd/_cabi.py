@@ -64,7 +64,10 @@ class PoseAdamArgs(C.Structure):
         "cam_rot_delta", "cam_trans_delta", "exposure_a", "exposure_b", "grad_rot", "grad_trans",
         "grad_a", "grad_b", "exp_avg", "exp_avg_sq", "T", "converged")]
         + [("step", C.c_int32)] + [(n, C.c_float) for n in (
-            "lr_rot", "lr_trans", "lr_a", "lr_b", "beta1", "beta2", "eps", "converged_threshold")])
+            "lr_rot", "lr_trans", "lr_a", "lr_b", "beta1", "beta2", "eps", "converged_threshold")]
+        + [("tau_partials", _fp), ("num_tau_partials", C.c_int32), ("exposure_partials", _fp),
+           ("num_exposure_partials", C.c_int32), ("projection", _fp), ("viewmatrix_out", _fp),
+           ("projmatrix_out", _fp)])
 
 
 class MappingLossArgs(C.Structure):
@@ -93,7 +96,7 @@ class TrackingLossArgs(C.Structure):
 class TrackingIterArgs(C.Structure):
     _fields_ = [("fwd", ForwardArgs), ("bwd", _fp), ("grad_image", _fp), ("grad_tau", _fp),
                 ("grad_exposure", _fp), ("one", _fp), ("loss", TrackingLossArgs),
-                ("adam", PoseAdamArgs)]
+                ("adam", PoseAdamArgs), ("camera_matrices_valid", C.c_int32)]
 
 
 class SketchResidualArgs(C.Structure):

@@ -570,7 +570,7 @@ __global__ __launch_bounds__(384) void k_tau_reduce(KB B, int nblk) {
 }
 
 // ---------------------------------------------------------------------------------
-int launch_backward(const KP& P, const KB& B, hipStream_t st) {
+int launch_backward(const KP& P, const KB& B, hipStream_t st, bool skip_tau_reduce) {
   if (B.sketch_mode != 0) {
     const size_t HW = (size_t)P.W * P.H;
     const size_t nacc = (size_t)B.stack_dim * B.sketch_dim * 6;
@@ -586,7 +586,7 @@ int launch_backward(const KP& P, const KB& B, hipStream_t st) {
   }
   const int npre = (P.N + kPreBlock - 1) / kPreBlock;
   launch("preprocess_bwd", k_preprocess_bwd, dim3(npre), dim3(kPreBlock), st, P, B);
-  launch("tau_reduce", k_tau_reduce, dim3(1), dim3(384), st, B, npre);
+  if (!skip_tau_reduce) launch("tau_reduce", k_tau_reduce, dim3(1), dim3(384), st, B, npre);
   return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
 }
 

@@ -24,7 +24,7 @@ void profile_push(const char* name, hipEvent_t a, hipEvent_t b) {
 namespace mgs {
 int launch_forward_project(const KP& P, hipStream_t st);
 int launch_forward_blend(const KP& P, hipStream_t st);
-int launch_backward(const KP& P, const KB& B, hipStream_t st);
+int launch_backward(const KP& P, const KB& B, hipStream_t st, bool skip_tau_reduce);
 int launch_knn(const float* pts, int n, float* out, void* scratch, hipStream_t st);
 uint64_t knn_scratch_bytes(int n);
 }  // namespace mgs
@@ -155,7 +155,11 @@ int32_t mgs_raster_forward_blend(const mgs_forward_args* args, void* stream) {
   return launch_forward_blend(P, (hipStream_t)stream);
 }
 
-int32_t mgs_raster_backward(const mgs_backward_args* args, void* stream) {
+extern "C" int32_t mgs_internal_track_loss_fused(const mgs_tracking_loss_args* a, int32_t* nblk_out, void* stream);
+
+// skip_tau_reduce: the caller sums tau_partial itself (*tau_partials / *num_partials are set)
+static int32_t raster_backward_impl(const mgs_backward_args* args, void* stream, bool skip_tau_reduce,
+                                    const float** tau_partials, int32_t* num_partials) {
   if (!args) return MGS_ERR_BAD_ARGUMENT;
   KP P;
   const int rc = fill_kp(args->fwd, true, false, P);
@@ -188,7 +192,13 @@ int32_t mgs_raster_backward(const mgs_backward_args* args, void* stream) {
   char* sw = (char*)args->sketch_ws;
   B.pix_jac = sw ? (float*)(sw + L.pix_jac) : nullptr;
   B.splat_jac = sw ? (float*)(sw + L.splat_jac) : nullptr;
-  return launch_backward(P, B, (hipStream_t)stream);
+  if (tau_partials) *tau_partials = B.tau_partial;
+  if (num_partials) *num_partials = (P.N + kPreBlock - 1) / kPreBlock;
+  return launch_backward(P, B, (hipStream_t)stream, skip_tau_reduce);
+}
+
+int32_t mgs_raster_backward(const mgs_backward_args* args, void* stream) {
+  return raster_backward_impl(args, stream, false, nullptr, nullptr);
 }
 
 int32_t mgs_tracking_iteration(const mgs_tracking_iter_args* args, void* stream) {
@@ -196,29 +206,39 @@ int32_t mgs_tracking_iteration(const mgs_tracking_iter_args* args, void* stream)
       !args->one || !args->adam.T || !args->fwd.viewmatrix || !args->fwd.projmatrix)
     return MGS_ERR_BAD_ARGUMENT;
   if (args->fwd.shape.pair_capacity < 1) return MGS_ERR_BAD_ARGUMENT;
-  int32_t rc = mgs_camera_from_pose(args->adam.T, args->fwd.projmatrix_raw,
-                                    const_cast<float*>(args->fwd.viewmatrix),
-                                    const_cast<float*>(args->fwd.projmatrix), stream);
-  if (rc != MGS_OK) return rc;
+  // 14 launches: camera matrices (unless the caller says they are valid - the previous
+  // iteration's Adam kernel has already written them), 7 forward, 2 loss, 2 backward, 1 Adam + update_pose
+  // (which also sums the tau / exposure block partials and refreshes the camera matrices).
+  int32_t rc = MGS_OK;
+  if (!args->camera_matrices_valid) {
+    rc = mgs_camera_from_pose(args->adam.T, args->fwd.projmatrix_raw, const_cast<float*>(args->fwd.viewmatrix),
+                              const_cast<float*>(args->fwd.projmatrix), stream);
+    if (rc != MGS_OK) return rc;
+  }
   if ((rc = mgs_raster_forward_project(&args->fwd, stream)) != MGS_OK) return rc;
   if ((rc = mgs_raster_forward_blend(&args->fwd, stream)) != MGS_OK) return rc;
   mgs_tracking_loss_args L = args->loss;
   L.image = args->fwd.out_color; L.opacity = args->fwd.out_opacity;
   L.grad_out = args->one; L.grad_image = args->grad_image;
   L.grad_a = args->grad_exposure; L.grad_b = args->grad_exposure + 1;
-  if ((rc = mgs_tracking_loss_forward(&L, stream)) != MGS_OK) return rc;
-  if ((rc = mgs_tracking_loss_backward(&L, stream)) != MGS_OK) return rc;
+  int32_t nblk = 0;
+  if ((rc = mgs_internal_track_loss_fused(&L, &nblk, stream)) != MGS_OK) return rc;
   mgs_backward_args B;
   memset(&B, 0, sizeof(B));
   B.fwd = args->fwd;
   B.grad_color = args->grad_image;
   B.bwd = args->bwd;
   B.grad_tau = args->grad_tau;
-  if ((rc = mgs_raster_backward(&B, stream)) != MGS_OK) return rc;
+  const float* tau_partials = nullptr;
+  int32_t npre = 0;
+  if ((rc = raster_backward_impl(&B, stream, true, &tau_partials, &npre)) != MGS_OK) return rc;
   mgs_pose_adam_args A = args->adam;
-  A.grad_trans = args->grad_tau; A.grad_rot = args->grad_tau + 3;
-  A.grad_a = A.exposure_a ? args->grad_exposure : nullptr;
-  A.grad_b = A.exposure_b ? args->grad_exposure + 1 : nullptr;
+  A.grad_trans = nullptr; A.grad_rot = nullptr; A.grad_a = nullptr; A.grad_b = nullptr;
+  A.tau_partials = tau_partials; A.num_tau_partials = npre;
+  A.exposure_partials = L.partial + nblk; A.num_exposure_partials = nblk;
+  A.projection = args->fwd.projmatrix_raw;
+  A.viewmatrix_out = const_cast<float*>(args->fwd.viewmatrix);
+  A.projmatrix_out = const_cast<float*>(args->fwd.projmatrix);
   return mgs_pose_adam_step(&A, stream);
 }
 

@@ -38,10 +38,32 @@ __device__ inline void so3_exp_V(const float th[3], float R[9], float V[9]) {
   }
 }
 
-__global__ void k_pose_adam_update(mgs_pose_adam_args A) {
+__global__ __launch_bounds__(512) void k_pose_adam_update(mgs_pose_adam_args A) {
+  // optional fused reductions: wave w < 6 sums component w of the tau partials, waves 6 / 7 the
+  // two exposure sums, each in a fixed order (independent strided loads, then a wave sum)
+  __shared__ float s_g[8];     // rot(3), trans(3), a, b
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (A.tau_partials && wave < 6) {
+    float v = 0.f;
+#pragma unroll 8
+    for (int i = lane; i < A.num_tau_partials; i += 64) v += A.tau_partials[i * 6 + wave];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if (lane == 0) s_g[wave < 3 ? 3 + wave : wave - 3] = v;      // tau = [rho (trans); theta (rot)]
+  }
+  if (A.exposure_partials && wave >= 6) {
+    const int c = wave - 6;
+    float v = 0.f;
+#pragma unroll 8
+    for (int i = lane; i < A.num_exposure_partials; i += 64) v += A.exposure_partials[c * A.num_exposure_partials + i];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if (lane == 0) s_g[6 + c] = v;
+  }
+  __syncthreads();
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   float* P[4] = {A.cam_rot_delta, A.cam_trans_delta, A.exposure_a, A.exposure_b};
-  const float* G[4] = {A.grad_rot, A.grad_trans, A.grad_a, A.grad_b};
+  const float* G[4] = {A.tau_partials ? &s_g[0] : A.grad_rot, A.tau_partials ? &s_g[3] : A.grad_trans,
+                       A.exposure_partials ? (A.exposure_a ? &s_g[6] : nullptr) : A.grad_a,
+                       A.exposure_partials ? (A.exposure_b ? &s_g[7] : nullptr) : A.grad_b};
   const float lr[4] = {A.lr_rot, A.lr_trans, A.lr_a, A.lr_b};
   const int len[4] = {3, 3, 1, 1};
   const float bc1 = 1.f - powf(A.beta1, (float)A.step);
@@ -75,6 +97,15 @@ __global__ void k_pose_adam_update(mgs_pose_adam_args A) {
                      rho[2] * rho[2];
     if (A.converged) *A.converged = n2 < A.converged_threshold * A.converged_threshold ? 1 : 0;
     for (int i = 0; i < 3; i++) { A.cam_rot_delta[i] = 0.f; A.cam_trans_delta[i] = 0.f; }
+    if (A.viewmatrix_out && A.projmatrix_out && A.projection) {   // matrices of the updated pose
+      for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+          float acc = 0.f;
+          for (int k = 0; k < 4; k++) acc += A.T[4 * k + i] * A.projection[4 * k + j];
+          A.projmatrix_out[4 * i + j] = acc;
+          A.viewmatrix_out[4 * i + j] = A.T[4 * j + i];
+        }
+    }
   }
 }
 
@@ -145,12 +176,26 @@ __global__ __launch_bounds__(kLossBlock) void k_track_loss_finish(mgs_tracking_l
 }
 
 // grad_image = gout/loss * h * h' * om * gain ; partial sums for d/da, d/db
-__global__ __launch_bounds__(kLossBlock) void k_track_loss_bwd(mgs_tracking_loss_args A) {
+// nfwd > 0 (fused form, mgs_tracking_iteration): the forward's nfwd block sums are added up
+// here by every workgroup (no k_track_loss_finish launch) and the exposure partials go
+// BEHIND them in `partial` (summed by k_pose_adam_update, no k_track_loss_bwd_finish launch).
+__global__ __launch_bounds__(kLossBlock) void k_track_loss_bwd(mgs_tracking_loss_args A, int nfwd) {
   __shared__ float s_red[kLossBlock / 64];
   const float a = A.exposure_a[0];
   const float gain = fabsf(a) + A.exposure_eps, bias = A.exposure_b[0];
   const float sgn = a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f);
-  const float k = A.grad_out[0] * A.scalars[1];
+  float inv_loss = 0.f;
+  if (nfwd > 0) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nfwd; i += kLossBlock) acc += A.partial[i];
+    const float l = sqrtf(block_sum(acc, s_red));
+    inv_loss = l > 0.f ? 1.f / l : 0.f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { A.scalars[0] = l; A.scalars[1] = inv_loss; }
+    __syncthreads();
+  } else {
+    inv_loss = A.scalars[1];
+  }
+  const float k = A.grad_out[0] * inv_loss;
   const size_t HW = (size_t)A.num_pixels;
   float ga = 0.f, gb = 0.f;
   for (size_t p = (size_t)blockIdx.x * kLossBlock + threadIdx.x; p < HW; p += (size_t)gridDim.x * kLossBlock) {
@@ -169,8 +214,8 @@ __global__ __launch_bounds__(kLossBlock) void k_track_loss_bwd(mgs_tracking_loss
   const float ta = block_sum(ga, s_red);
   const float tb = block_sum(gb, s_red);
   if (threadIdx.x == 0) {
-    A.partial[blockIdx.x] = ta * sgn;
-    A.partial[gridDim.x + blockIdx.x] = tb;
+    A.partial[nfwd + blockIdx.x] = ta * sgn;
+    A.partial[nfwd + gridDim.x + blockIdx.x] = tb;
   }
 }
 
@@ -486,7 +531,7 @@ int32_t mgs_pose_adam_step(const mgs_pose_adam_args* a, void* stream) {
   if (!a || !a->cam_rot_delta || !a->cam_trans_delta || !a->exp_avg || !a->exp_avg_sq || a->step < 1)
     return MGS_ERR_BAD_ARGUMENT;
   if ((a->grad_a && !a->exposure_a) || (a->grad_b && !a->exposure_b)) return MGS_ERR_BAD_ARGUMENT;
-  launch("pose_adam_update", k_pose_adam_update, dim3(1), dim3(64), (hipStream_t)stream, *a);
+  launch("pose_adam_update", k_pose_adam_update, dim3(1), dim3(512), (hipStream_t)stream, *a);
   return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
@@ -557,7 +602,20 @@ int32_t mgs_sketch_residual(const mgs_sketch_residual_args* a, void* stream) {
   return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
-int32_t mgs_tracking_loss_partial_count(int64_t num_pixels) { return 2 * loss_blocks(num_pixels); }
+int32_t mgs_tracking_loss_partial_count(int64_t num_pixels) { return 3 * loss_blocks(num_pixels); }
+
+// Fused form used by mgs_tracking_iteration: forward sums + backward in two launches; the
+// exposure partials ([2, nblk]) start at partial + nblk.
+int32_t mgs_internal_track_loss_fused(const mgs_tracking_loss_args* a, int32_t* nblk_out, void* stream) {
+  if (!a || !a->image || !a->opacity || !a->gt || !a->exposure_a || !a->exposure_b || !a->partial ||
+      !a->scalars || !a->grad_out || !a->grad_image || a->num_pixels < 1)
+    return MGS_ERR_BAD_ARGUMENT;
+  const int nb = loss_blocks(a->num_pixels);
+  launch("track_loss_fwd", k_track_loss_fwd, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a);
+  launch("track_loss_bwd", k_track_loss_bwd, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a, nb);
+  if (nblk_out) *nblk_out = nb;
+  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+}
 
 int32_t mgs_tracking_loss_forward(const mgs_tracking_loss_args* a, void* stream) {
   if (!a || !a->image || !a->opacity || !a->gt || !a->exposure_a || !a->exposure_b || !a->partial ||
@@ -574,7 +632,7 @@ int32_t mgs_tracking_loss_backward(const mgs_tracking_loss_args* a, void* stream
       !a->scalars || !a->grad_out || !a->grad_image || !a->grad_a || !a->grad_b || a->num_pixels < 1)
     return MGS_ERR_BAD_ARGUMENT;
   const int nb = loss_blocks(a->num_pixels);
-  launch("track_loss_bwd", k_track_loss_bwd, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a);
+  launch("track_loss_bwd", k_track_loss_bwd, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a, 0);
   launch("track_loss_bwd_fin", k_track_loss_bwd_finish, dim3(1), dim3(kLossBlock), (hipStream_t)stream, *a, nb);
   return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
 }

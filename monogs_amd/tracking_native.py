@@ -114,6 +114,7 @@ class NativeTracker:
             lr_rot, lr_trans, lr_a, lr_b, betas[0], betas[1], eps, converged_threshold)
         self.args = a
         self.t = 0
+        self._matrices_fresh = False
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
@@ -163,6 +164,7 @@ class NativeTracker:
         so.key = (self.so_seed * 0x9E3779B97F4A7C15 + self.so_t) & 0xFFFFFFFFFFFFFFFF
         _cabi.check(_cabi.lib().mgs_tracking_iteration_second_order(C.byref(so), self._stream()),
                     "mgs_tracking_iteration_second_order")
+        self._matrices_fresh = False     # the LM step moved T
         return self.lm_state
 
     @property
@@ -176,8 +178,10 @@ class NativeTracker:
         """Enqueue one iteration; returns the device convergence flag (int32[1])."""
         self.t += 1
         self.args.adam.step = self.t
+        self.args.camera_matrices_valid = 1 if self._matrices_fresh else 0
         _cabi.check(_cabi.lib().mgs_tracking_iteration(C.byref(self.args), self._stream()),
                     "mgs_tracking_iteration")
+        self._matrices_fresh = True      # the Adam kernel wrote the matrices of the updated pose
         return self.converged
 
     @property
