@@ -178,8 +178,9 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
     unsigned int mask4 = 0;
     if (lane < nb) {
       const int k = start + base + lane;
-      const unsigned int id = (unsigned int)P.keys[k];
-      slot = pair_slot_base(P, (int)id) + (int)P.payload[k];
+      const unsigned int lo = (unsigned int)P.keys[k];
+      const unsigned int id = P.pack ? lo >> kPackBits : lo;
+      slot = pair_slot_base(P, (int)id) + (int)(P.pack ? (lo & ((1u << kPackBits) - 1u)) : P.payload[k]);
       const float4* src = reinterpret_cast<const float4*>(P.rec + id);
       const float4 qa = src[0], qb = src[1];
       const float4 q2 = src[2];

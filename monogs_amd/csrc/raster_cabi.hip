@@ -55,6 +55,7 @@ int fill_kp(const mgs_forward_args& a, bool need_bins, bool need_outputs, KP& P)
   P.N = s.num_gaussians; P.W = s.width; P.H = s.height;
   P.grid_x = (s.width + kTile - 1) / kTile; P.grid_y = (s.height + kTile - 1) / kTile;
   P.T = P.grid_x * P.grid_y;
+  P.pack = (s.num_gaussians <= kPackMaxN && P.T <= (1 << kPackBits)) ? 1 : 0;
   P.deg = s.sh_degree; P.K = a.shs ? s.sh_coeffs : 0; P.cap = s.pair_capacity;
   P.tanfovx = s.tanfovx; P.tanfovy = s.tanfovy;
   P.focal_x = s.width / (2.0f * s.tanfovx); P.focal_y = s.height / (2.0f * s.tanfovy);

@@ -78,8 +78,12 @@ __device__ __forceinline__ void bin_one_pair(const KP& P, int* s_tile, int emit,
                                              unsigned long long key, unsigned int j) {
   const int pos = atomicAdd(&s_tile[t], 1);
   if (emit && pos < P.cap) {
-    P.keys[pos] = key;
-    P.payload[pos] = j;
+    if (P.pack) {
+      P.keys[pos] = (key & 0xFFFFFFFF00000000ull) | ((key & 0xFFFFFull) << kPackBits) | j;
+    } else {
+      P.keys[pos] = key;
+      P.payload[pos] = j;
+    }
   }
 }
 
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(64 * kColGroups) void k_bin_colsum(KP P, int nblk) 
 // workgroup barrier - LDS operations of one wave execute in order - only the few with
 // larger blocks are bracketed by __syncthreads().  WAVE_LOCAL = false (HBM fallback for
 // oversized tiles) keeps a barrier after every sub-stage.
-template <bool WAVE_LOCAL, typename KP_, typename VP_>
+template <bool WAVE_LOCAL, bool HAS_VAL, typename KP_, typename VP_>
 __device__ __forceinline__ void bitonic_sort(KP_ key, VP_ val, int n, int tid) {
   int m = 2;
   while (m < n) m <<= 1;
@@ -451,13 +455,16 @@ __device__ __forceinline__ void bitonic_sort(KP_ key, VP_ val, int n, int tid) {
           pair_of(wave * cpw + c, lo[u], hi[u]);
           if (hi[u] >= n) lo[u] = -1;
         }
-        if (lo[u] >= 0) { a[u] = key[lo[u]]; b[u] = key[hi[u]]; va[u] = val[lo[u]]; vb[u] = val[hi[u]]; }
+        if (lo[u] >= 0) {
+          a[u] = key[lo[u]]; b[u] = key[hi[u]];
+          if constexpr (HAS_VAL) { va[u] = val[lo[u]]; vb[u] = val[hi[u]]; }
+        }
       }
 #pragma unroll
       for (int u = 0; u < kMaxCmp; u++) {
         if (lo[u] >= 0 && a[u] > b[u]) {
           key[lo[u]] = b[u]; key[hi[u]] = a[u];
-          val[lo[u]] = vb[u]; val[hi[u]] = va[u];
+          if constexpr (HAS_VAL) { val[lo[u]] = vb[u]; val[hi[u]] = va[u]; }
         }
       }
     }
@@ -486,10 +493,10 @@ __device__ __forceinline__ void bitonic_sort(KP_ key, VP_ val, int n, int tid) {
 // Two launches by tile size class, so that the common small tiles run at 12 KB of LDS per
 // workgroup (high occupancy) and only crowded tiles pay for 48 KB; tiles beyond 4096 pairs
 // sort in place in HBM with the same network.
-template <int CAP, int MIN_N>
+template <int CAP, int MIN_N, bool PACKED>
 __global__ __launch_bounds__(256) void k_tile_sort(KP P) {
   __shared__ unsigned long long s_key[CAP];
-  __shared__ unsigned int s_val[CAP];
+  __shared__ unsigned int s_val[PACKED ? 1 : CAP];
   const int tid = threadIdx.x;
   for (int tile = blockIdx.x; tile < P.T; tile += gridDim.x) {
   int start = P.tile_offset[tile], end = P.tile_offset[tile + 1];
@@ -502,14 +509,20 @@ __global__ __launch_bounds__(256) void k_tile_sort(KP P) {
   }
   if (n <= 1 || n <= MIN_N || (MIN_N == 0 && n > CAP)) continue;   // workgroup-uniform
   unsigned long long* gk = P.keys + start;
-  unsigned int* gv = P.payload + start;
+  unsigned int* gv = PACKED ? nullptr : P.payload + start;
   if (n <= CAP) {
     __syncthreads();      // the previous tile of this workgroup is done with the LDS arrays
-    for (int i = tid; i < n; i += 256) { s_key[i] = gk[i]; s_val[i] = gv[i]; }
-    bitonic_sort<true>(s_key, s_val, n, tid);
-    for (int i = tid; i < n; i += 256) { gk[i] = s_key[i]; gv[i] = s_val[i]; }
+    for (int i = tid; i < n; i += 256) {
+      s_key[i] = gk[i];
+      if constexpr (!PACKED) s_val[i] = gv[i];
+    }
+    bitonic_sort<true, !PACKED>(s_key, s_val, n, tid);
+    for (int i = tid; i < n; i += 256) {
+      gk[i] = s_key[i];
+      if constexpr (!PACKED) gv[i] = s_val[i];
+    }
   } else {
-    bitonic_sort<false>(gk, gv, n, tid);
+    bitonic_sort<false, !PACKED>(gk, gv, n, tid);
   }
   }
 }
@@ -540,8 +553,9 @@ constexpr int kFwdChunk = 4;       // the four quadrants of a tile share an XCD 
 static_assert(kSeg == 64, "one staged record per lane");
 
 __device__ __forceinline__ unsigned int fwd_load_id(const KP& P, int start, int n, int k) {
-  // low half of the 64-bit key = Gaussian id
-  return k < n ? reinterpret_cast<const unsigned int*>(P.keys + start)[2 * (size_t)k] : 0u;
+  // low half of the 64-bit key = Gaussian id (<< kPackBits | pair index when packed)
+  const unsigned int lo = k < n ? reinterpret_cast<const unsigned int*>(P.keys + start)[2 * (size_t)k] : 0u;
+  return P.pack ? lo >> kPackBits : lo;
 }
 
 // m &= ~(1 << j) on a wave-uniform 64-bit mask in ONE scalar instruction (the C form
@@ -753,9 +767,14 @@ int launch_forward_blend(const KP& P, hipStream_t st) {
       return MGS_ERR_LAUNCH;
     launch("bin_emit", k_bin, dim3((P.N + 255) / 256), dim3(256), st, P, 1);
   }
-  launch("tile_sort", k_tile_sort<1024, 0>, dim3(P.T), dim3(256), st, P);
-  // crowded tiles are rare: a small grid walks the tile list instead of T mostly idle workgroups
-  launch("tile_sort_big", k_tile_sort<4096, 1024>, dim3(min(P.T, 256)), dim3(256), st, P);
+  // crowded tiles are rare: for them a small grid walks the tile list instead of T mostly idle workgroups
+  if (P.pack) {
+    launch("tile_sort", k_tile_sort<1024, 0, true>, dim3(P.T), dim3(256), st, P);
+    launch("tile_sort_big", k_tile_sort<4096, 1024, true>, dim3(min(P.T, 256)), dim3(256), st, P);
+  } else {
+    launch("tile_sort", k_tile_sort<1024, 0, false>, dim3(P.T), dim3(256), st, P);
+    launch("tile_sort_big", k_tile_sort<4096, 1024, false>, dim3(min(P.T, 256)), dim3(256), st, P);
+  }
   launch("blend_fwd", k_blend_fwd, dim3(grid_pad(4 * P.T, kFwdChunk)), dim3(64), st, P);
   return check_launch();
 }

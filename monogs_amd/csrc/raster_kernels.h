@@ -13,6 +13,7 @@ namespace mgs {
 // by value (kernarg segment -> SGPRs).
 struct KP {
   int N, W, H, grid_x, grid_y, T, deg, K, cap;
+  int pack;                // 1: sort key low word = id << kPackBits | pair index (no payload array)
   float tanfovx, tanfovy, focal_x, focal_y, mod;
   const float *means, *scales, *rots, *covp, *opac, *shs, *precol;
   const float *V, *PM, *Praw, *campos, *bg;
@@ -85,6 +86,11 @@ struct Layout {
 
 constexpr int kScanBlock = 2048;   // elements per block in the pair_base scan
 constexpr int kPreBlock = 256;
+// Packed sort keys: when N <= 2^20 and T <= 2^12 the pair's index within its Gaussian fits
+// beside the Gaussian id in the low key word, so the per-tile sort moves 8 B per pair instead of
+// 12 B.  The order is unchanged: a Gaussian occurs once per tile, so (depth, id) is already unique.
+constexpr int kPackBits = 12;
+constexpr int kPackMaxN = 1 << 20;
 constexpr int kSeg = 64;            // splats per blend segment (checkpoint interval)
 constexpr int kBinBlocks = 512;    // workgroups of the LDS-privatised binning passes
 constexpr int kBinThreads = 1024;
