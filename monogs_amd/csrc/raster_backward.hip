@@ -160,50 +160,18 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
   __shared__ float4 s_coef[SKETCH ? kSeg : 1][9];   // per splat: 6 features x 6 tau components
   const int item = xcd_remap<kBwdChunk>(blockIdx.x), lane = threadIdx.x;
   if (item >= min(P.seg_offset[P.T], P.max_segs)) return;
-  const int tile = P.seg_tile[item];
-  const int seg = item - P.seg_offset[tile];
-  int start = P.tile_offset[tile], end = P.tile_offset[tile + 1];
-  start = min(start, P.cap); end = min(end, P.cap);
-  const int base = seg * kSeg;
-  const int nb = min(kSeg, end - start - base);
+  // One 16-B record per segment (written by the tile sort) instead of a chain of dependent
+  // loads: tile, index of the segment's first key, number of splats, position in the tile's list.
+  const int4 sr = P.seg_rec[item];
+  const int tile = sr.x, k0 = sr.y, nb = sr.z, base = sr.w;
   if (nb <= 0) return;
   const int tx = tile % P.grid_x, ty = tile / P.grid_x;
   // Pixel q of this lane lies in QUADRANT q of the tile: (qx + 8 (q & 1), qy + 8 (q >> 1)).
   const int qx = tx * kTile + (lane & 7), qy = ty * kTile + (lane >> 3);
   const size_t HW = (size_t)P.W * P.H;
-
-  // ---- stage the segment's records (one per lane): slot, raw conic, quadrant reach mask ---
-  int slot = -1;
-  {
-    unsigned int mask4 = 0;
-    if (lane < nb) {
-      const int k = start + base + lane;
-      const unsigned int lo = (unsigned int)P.keys[k];
-      const unsigned int id = P.pack ? lo >> kPackBits : lo;
-      slot = pair_slot_base(P, (int)id) + (int)(P.pack ? (lo & ((1u << kPackBits) - 1u)) : P.payload[k]);
-      const float4* src = reinterpret_cast<const float4*>(P.rec + id);
-      const float4 qa = src[0], qb = src[1];
-      const float4 q2 = src[2];
-      s_r0[lane] = make_float4(qa.x, qa.y, -0.5f * kLog2eB * qb.x, -kLog2eB * qb.y);
-      s_r1[lane] = make_float4(-0.5f * kLog2eB * qb.z, qa.w, q2.x, q2.y);   // (C', opacity, r, g)
-      s_r2[lane] = make_float2(q2.z, qa.z);                                  // (b, depth)
-      if constexpr (SKETCH) {
-        const float4* cj = reinterpret_cast<const float4*>(B.splat_jac + (size_t)id * 36);
-#pragma unroll
-        for (int i = 0; i < 9; i++) s_coef[lane][i] = cj[i];
-      }
-      const float qmax = splat_qmax(qa.w);
-      const float Wm = (float)(P.W - 1), Hm = (float)(P.H - 1);
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const float x0 = (float)(tx * kTile + 8 * (q & 1)), y0 = (float)(ty * kTile + 8 * (q >> 1));
-        if (x0 <= Wm && y0 <= Hm &&
-            box_reachable(qa.x, qa.y, qb.x, qb.y, qb.z, qmax, x0, y0, fminf(x0 + 7.f, Wm), fminf(y0 + 7.f, Hm)))
-          mask4 |= 1u << q;
-      }
-    }
-    s_mask[lane] = mask4;
-  }
+  // the key of this lane's splat is requested first; the ~60 per-pixel loads below are issued
+  // while it is in flight, and the record gather that depends on it comes after them
+  const unsigned int lo = lane < nb ? (unsigned int)P.keys[k0 + lane] : 0u;
 
   // ---- per-pixel state ----------------------------------------------------------------------
   // T (transmittance in front of the next splat) and the scalar
@@ -214,7 +182,7 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
   int last[4];
   float g0[4], g1[4], g2[4], gd[4], T[4], gS[4];
   const float bg0 = P.bg[0], bg1 = P.bg[1], bg2 = P.bg[2];
-  const float* ck = (seg > 0) ? P.ckpt + (size_t)item * (5 * 256) : nullptr;
+  const float* ck = (base > 0) ? P.ckpt + (size_t)item * (5 * 256) : nullptr;
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const int px = qx + 8 * (q & 1), py = qy + 8 * (q >> 1);
@@ -242,11 +210,42 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
     // that (unwritten) state into the arithmetic
     if (last[q] <= base) { T[q] = 0.f; gS[q] = 0.f; }
   }
-  // does any pixel of the tile reach this segment?
-  int ml = max(max(last[0], last[1]), max(last[2], last[3]));
+  // does any pixel of the tile reach this segment?  (one ballot instead of a shuffle tree)
+  const bool dead = __ballot(max(max(last[0], last[1]), max(last[2], last[3])) > base) == 0ull;
+
+  // ---- stage the segment's records (one per lane): slot, raw conic, quadrant reach mask ---
+  int slot = -1;
+  {
+    unsigned int mask4 = 0;
+    if (lane < nb) {
+      const unsigned int id = P.pack ? lo >> kPackBits : lo;
+      slot = pair_slot_base(P, (int)id) + (int)(P.pack ? (lo & ((1u << kPackBits) - 1u)) : P.payload[k0 + lane]);
+      if (!dead) {
+        const float4* src = reinterpret_cast<const float4*>(P.rec + id);
+        const float4 qa = src[0], qb = src[1];
+        const float4 q2 = src[2];
+        s_r0[lane] = make_float4(qa.x, qa.y, -0.5f * kLog2eB * qb.x, -kLog2eB * qb.y);
+        s_r1[lane] = make_float4(-0.5f * kLog2eB * qb.z, qa.w, q2.x, q2.y);   // (C', opacity, r, g)
+        s_r2[lane] = make_float2(q2.z, qa.z);                                  // (b, depth)
+        if constexpr (SKETCH) {
+          const float4* cj = reinterpret_cast<const float4*>(B.splat_jac + (size_t)id * 36);
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) ml = max(ml, __shfl_xor(ml, off));
-  if (base >= ml) {
+          for (int i = 0; i < 9; i++) s_coef[lane][i] = cj[i];
+        }
+        const float qmax = splat_qmax(qa.w);
+        const float Wm = (float)(P.W - 1), Hm = (float)(P.H - 1);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float x0 = (float)(tx * kTile + 8 * (q & 1)), y0 = (float)(ty * kTile + 8 * (q >> 1));
+          if (x0 <= Wm && y0 <= Hm &&
+              box_reachable(qa.x, qa.y, qb.x, qb.y, qb.z, qmax, x0, y0, fminf(x0 + 7.f, Wm), fminf(y0 + 7.f, Hm)))
+            mask4 |= 1u << q;
+        }
+      }
+    }
+    s_mask[lane] = mask4;
+  }
+  if (dead) {
     if (slot >= 0) {
       float4* dst = B.pair_grad + (size_t)slot * 3;
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);

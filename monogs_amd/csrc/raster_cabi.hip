@@ -83,7 +83,7 @@ int fill_kp(const mgs_forward_args& a, bool need_bins, bool need_outputs, KP& P)
   char* b = (char*)a.bins;
   P.keys = b ? (unsigned long long*)(b + L.keys) : nullptr;
   P.payload = b ? (unsigned int*)(b + L.payload) : nullptr;
-  P.seg_tile = b ? (int*)(b + L.seg_tile) : nullptr;
+  P.seg_rec = b ? (int4*)(b + L.seg_rec) : nullptr;
   P.ckpt = b ? (float*)(b + L.ckpt) : nullptr;
   P.max_segs = (int)L.max_segs;
   P.out_color = a.out_color; P.out_depth = a.out_depth; P.out_opacity = a.out_opacity;

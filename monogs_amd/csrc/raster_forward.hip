@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256) void k_tile_sort(KP P) {
   if (MIN_N == 0) {   // segment -> tile map for the segment-parallel backward
     const int s0 = P.seg_offset[tile], ns = (n + kSeg - 1) / kSeg;
     for (int i = tid; i < ns; i += 256)
-      if (s0 + i < P.max_segs) P.seg_tile[s0 + i] = tile;
+      if (s0 + i < P.max_segs) P.seg_rec[s0 + i] = make_int4(tile, start + i * kSeg, min(kSeg, n - i * kSeg), i * kSeg);
   }
   if (n <= 1 || n <= MIN_N || (MIN_N == 0 && n > CAP)) continue;   // workgroup-uniform
   unsigned long long* gk = P.keys + start;

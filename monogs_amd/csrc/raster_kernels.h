@@ -35,7 +35,7 @@ struct KP {
   // bins workspace
   unsigned long long* keys;
   unsigned int* payload;
-  int* seg_tile;           // segment -> tile
+  int4* seg_rec;           // segment -> (tile, first key index, splats in the segment, base)
   float* ckpt;             // per segment: [5][256] blend state (T, C0, C1, C2, D) before its first splat
   int max_segs;
   // forward outputs
@@ -79,7 +79,7 @@ inline uint64_t align_up(uint64_t v) { return (v + kAlign - 1) / kAlign * kAlign
 struct Layout {
   uint64_t rec, pair_count, pair_off, block_prefix, scan_tmp, tile_count, tile_offset, tile_cursor, bin_table, final_T, final_C,
       n_contrib, seg_offset, counters, geom_bytes;
-  uint64_t keys, payload, seg_tile, ckpt, max_segs, bins_bytes;
+  uint64_t keys, payload, seg_rec, ckpt, max_segs, bins_bytes;
   uint64_t pair_grad, tau_partial, bwd_bytes;
   uint64_t pix_jac, splat_jac, sketch_bytes;
 };
@@ -125,7 +125,7 @@ inline Layout make_layout(const mgs_raster_shape& s) {
   L.keys = o; o = align_up(o + cap * 8);
   L.payload = o; o = align_up(o + cap * 4);
   L.max_segs = cap / kSeg + T;
-  L.seg_tile = o; o = align_up(o + L.max_segs * 4);
+  L.seg_rec = o; o = align_up(o + L.max_segs * 16);
   L.ckpt = o; o = align_up(o + L.max_segs * 5 * 256 * 4);
   L.bins_bytes = o;
   o = 0;
