@@ -47,7 +47,7 @@ with open(f"{out}/pmc_fetch_write_per_kernel.txt", "w") as fh:
         traffic[k] = int((2 * fe + wr) * 1024)
         fh.write(f"{k} {len(v['FETCH_SIZE'])} {fe:.1f} {wr:.1f} {(2 * fe + wr) * 1024 / 1e6:.1f} {(fe + wr) * 1024 / 1e6:.1f}\n")
 names = {"k_blend_bwd<false>": "blend_bwd", "k_blend_fwd": "blend_fwd", "k_preprocess_bwd": "preprocess_bwd",
-         "k_preprocess": "preprocess", "k_tile_sort<1024, 0>": "tile_sort", "k_bin_lds": "bin_emit"}
+         "k_preprocess": "preprocess", "k_tile_sort<1024, 0, true>": "tile_sort", "k_tile_sort<1024, 0, false>": "tile_sort", "k_bin_lds": "bin_emit"}
 json.dump({"workload": "SYN-C 300000 @ 640x480",
            "source": "profiles/collect.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
            "correction": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes: gfx950 FETCH_SIZE counts half of wide "
