@@ -304,7 +304,7 @@ def main():
             t_cpu += time.perf_counter() - t1
             reps += 1
         cpu_baseline = {"value": round(reps / t_cpu, 3), "unit": "frames/s",
-                        "cores": os.cpu_count(), "kind": "port",
+                        "cores": em.num_threads(), "kind": "port",
                         "sample": f"{reps} fwd+bwd of the same SYN-C workload "
                                   f"({N} Gaussians @ {W}x{H}), OpenMP C++ host emulation "
                                   "(oracle/host_emul.cpp)"}

@@ -15,6 +15,7 @@
 // Build: g++ -O2 -fopenmp -shared -fPIC oracle/host_emul.cpp -o oracle/libhost_emul.so
 #include <algorithm>
 #include <cstdint>
+#include <omp.h>
 #include <cstring>
 #include <vector>
 
@@ -216,5 +217,8 @@ void emul_backward(void* h, const float* bg, const float* means3D, const float* 
   }
   for (int k = 0; k < 6; k++) dtau[k] = (float)tau[k];
 }
+
+// number of OpenMP threads the emulation runs on (bench.py reports it as cpu_baseline.cores)
+int emul_num_threads() { return omp_get_max_threads(); }
 
 }  // extern "C"

@@ -33,6 +33,7 @@ def lib():
             build()
         _lib = C.CDLL(_SO)
         _lib.emul_create.restype = C.c_void_p
+        _lib.emul_num_threads.restype = C.c_int
         _lib.emul_destroy.argtypes = [C.c_void_p]
         _lib.emul_forward.restype = C.c_int64
     return _lib
@@ -50,6 +51,11 @@ class HostEmul:
 
     def __init__(self):
         self.h = C.c_void_p(lib().emul_create())
+
+    @staticmethod
+    def num_threads() -> int:
+        """OpenMP threads the emulation runs on (omp_get_max_threads)."""
+        return int(lib().emul_num_threads())
 
     def __del__(self):
         try:
