@@ -373,8 +373,10 @@ int32_t mgs_sketch_residual(const mgs_sketch_residual_args* args, void* stream);
 
 /* One second-order iteration as a fixed launch sequence (no host round trip): camera
  * matrices from T -> forward -> zero accumulators -> mgs_sketch_assign(key) ->
- * mgs_sketch_residual -> pose-only backward in sketch mode (grad_sketch_dtau via the compact
- * bucket map) -> mgs_lm_solve_step with the device-resident trust-region state.
+ * mgs_sketch_residual -> Jacobian-only backward in sketch mode (grad_sketch_dtau via the compact
+ * bucket map; the per-splat sums, the per-Gaussian chain and grad_tau are skipped: the LM step
+ * consumes the sketched Jacobian alone) -> mgs_lm_solve_step with the device-resident
+ * trust-region state.
  * `base` as for mgs_tracking_iteration (its adam block is unused except T / exposure);
  * `accum` holds stack*sketch*9 + 4 floats: Sf[d] | sj_exposure[d,2] | sj_tau[d,6] | l1, pad. */
 typedef struct mgs_tracking_so_args {

@@ -151,8 +151,12 @@ __device__ __forceinline__ int pair_slot_base(const KP& P, int idx) {
 typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr float kLog2eB = 1.4426950408889634f;
 
-template <bool SKETCH>
+// JONLY (sketch mode only): nothing but the per-pixel pose-Jacobian rows is wanted - the
+// second-order tracking iteration uses grad_sketch_dtau alone (slam_frontend.py:654-669), so
+// the per-splat sums, their reduction and the pair records are skipped altogether.
+template <bool SKETCH, bool JONLY = false>
 __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
+  static_assert(SKETCH || !JONLY, "JONLY is a sketch-mode variant");
   static_assert(kSeg == 64, "one staged record per lane");
   __shared__ float4 s_r0[kSeg], s_r1[kSeg];
   __shared__ float2 s_r2[kSeg];
@@ -219,7 +223,8 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
     unsigned int mask4 = 0;
     if (lane < nb) {
       const unsigned int id = P.pack ? lo >> kPackBits : lo;
-      slot = pair_slot_base(P, (int)id) + (int)(P.pack ? (lo & ((1u << kPackBits) - 1u)) : P.payload[k0 + lane]);
+      if constexpr (!JONLY)
+        slot = pair_slot_base(P, (int)id) + (int)(P.pack ? (lo & ((1u << kPackBits) - 1u)) : P.payload[k0 + lane]);
       if (!dead) {
         const float4* src = reinterpret_cast<const float4*>(P.rec + id);
         const float4 qa = src[0], qb = src[1];
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
     s_mask[lane] = mask4;
   }
   if (dead) {
-    if (slot >= 0) {
+    if (!JONLY && slot >= 0) {
       float4* dst = B.pair_grad + (size_t)slot * 3;
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       dst[0] = z; dst[1] = z; dst[2] = z;
@@ -312,13 +317,15 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
       T[q] *= om;
       const float Wt = k ? ar * dA : 0.f;
       const v2f Wxy = v2f{Wt, Wt} * d;                // (W dx, W dy)
-      r0 += Wt;
-      R12 += Wxy;
-      R34 = __builtin_elementwise_fma(v2f{Wxy.x, Wxy.x}, d, R34);
-      r5 = __builtin_fmaf(Wxy.y, d.y, r5);
-      const v2f ww = {w, w};
-      R67 = __builtin_elementwise_fma(ww, G01[q], R67);
-      R89 = __builtin_elementwise_fma(ww, G2d[q], R89);
+      if constexpr (!JONLY) {
+        r0 += Wt;
+        R12 += Wxy;
+        R34 = __builtin_elementwise_fma(v2f{Wxy.x, Wxy.x}, d, R34);
+        r5 = __builtin_fmaf(Wxy.y, d.y, r5);
+        const v2f ww = {w, w};
+        R67 = __builtin_elementwise_fma(ww, G01[q], R67);
+        R89 = __builtin_elementwise_fma(ww, G2d[q], R89);
+      }
       if constexpr (SKETCH) {
         // J_t += W (c0 dx + c1 dy + c2 dx^2 + c3 dx dy + c4 dy^2) + (w dL/dD) c5 for the six tau
         // components: the splat's 36 coefficients are staged in LDS in feature-major order, so two
@@ -333,7 +340,7 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
         }
       }
     }
-    if (any) {
+    if (!JONLY && any) {
       // the ten wave totals land in ten different lanes; each stores its own dword of the
       // pair's record (slot of splat j broadcast from lane j): one store instruction per splat
       float mres, eres;
@@ -358,7 +365,7 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
     }
   }
   // splats of the segment that no pixel reached: zero record
-  if (slot >= 0 && !((written >> lane) & 1ull)) {
+  if (!JONLY && slot >= 0 && !((written >> lane) & 1ull)) {
     float4* dst = B.pair_grad + (size_t)slot * 3;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     dst[0] = z; dst[1] = z; dst[2] = z;
@@ -579,8 +586,12 @@ int launch_backward(const KP& P, const KB& B, hipStream_t st, bool skip_tau_redu
         hipMemsetAsync(B.g_sketch, 0, nacc * sizeof(float), st) != hipSuccess)
       return MGS_ERR_LAUNCH;
     launch("sketch_prep", k_sketch_prep, dim3((P.N + kPreBlock - 1) / kPreBlock), dim3(kPreBlock), st, P, B);
-    launch("blend_bwd_sketch", k_blend_bwd<true>, dim3(grid_pad(P.max_segs, kBwdChunk)), dim3(64), st, P, B);
+    if (B.sketch_only)
+      launch("blend_bwd_sketch", k_blend_bwd<true, true>, dim3(grid_pad(P.max_segs, kBwdChunk)), dim3(64), st, P, B);
+    else
+      launch("blend_bwd_sketch", k_blend_bwd<true, false>, dim3(grid_pad(P.max_segs, kBwdChunk)), dim3(64), st, P, B);
     launch_smem("sketch_bucket", k_sketch_bucket, dim3(kBucketBlocks), dim3(256), nacc * sizeof(float), st, P, B);
+    if (B.sketch_only) return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
   } else {
     launch("blend_bwd", k_blend_bwd<false>, dim3(grid_pad(P.max_segs, kBwdChunk)), dim3(64), st, P, B);
   }

@@ -160,7 +160,8 @@ extern "C" int32_t mgs_internal_track_loss_fused(const mgs_tracking_loss_args* a
 
 // skip_tau_reduce: the caller sums tau_partial itself (*tau_partials / *num_partials are set)
 static int32_t raster_backward_impl(const mgs_backward_args* args, void* stream, bool skip_tau_reduce,
-                                    const float** tau_partials, int32_t* num_partials) {
+                                    const float** tau_partials, int32_t* num_partials,
+                                    bool sketch_only = false) {
   if (!args) return MGS_ERR_BAD_ARGUMENT;
   KP P;
   const int rc = fill_kp(args->fwd, true, false, P);
@@ -188,6 +189,7 @@ static int32_t raster_backward_impl(const mgs_backward_args* args, void* stream,
   B.g_scales = args->grad_scales; B.g_rots = args->grad_rotations; B.g_cov = args->grad_cov3D;
   B.g_tau = args->grad_tau;
   B.sketch_mode = args->sketch_mode; B.sketch_dim = args->sketch_dim; B.stack_dim = args->stack_dim;
+  B.sketch_only = (sketch_only && args->sketch_mode != 0) ? 1 : 0;
   B.sketch_idx = args->sketch_indices; B.g_sketch = args->grad_sketch_dtau;
   B.sketch_flat = args->sketch_indices ? nullptr : args->sketch_bucket_flat;
   char* sw = (char*)args->sketch_ws;
@@ -282,7 +284,9 @@ int32_t mgs_tracking_iteration_second_order(const mgs_tracking_so_args* args, vo
   B.fwd = b.fwd; B.grad_color = b.grad_image; B.bwd = b.bwd; B.grad_tau = b.grad_tau;
   B.sketch_mode = 1; B.sketch_dim = args->sketch_dim; B.stack_dim = args->stack_dim;
   B.sketch_bucket_flat = args->bucket; B.grad_sketch_dtau = sj_tau; B.sketch_ws = args->sketch_ws;
-  if ((rc = mgs_raster_backward(&B, stream)) != MGS_OK) return rc;
+  // only grad_sketch_dtau is consumed by the LM step: J-only backward (no per-splat sums,
+  // no preprocess backward, no grad_tau)
+  if ((rc = raster_backward_impl(&B, stream, true, nullptr, nullptr, true)) != MGS_OK) return rc;
   mgs_lm_step_args L = args->lm;
   L.SJ = nullptr; L.sj_tau = sj_tau; L.sj_exposure = sj_exp; L.Sf = Sf; L.rows = d; L.loss = l1;
   L.T = b.adam.T; L.exposure_a = b.adam.exposure_a; L.exposure_b = b.adam.exposure_b;

@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void k_sketch_assign(long long m, int chunk, i
   }
 }
 
-constexpr int kSketchBlocks = 128;
+constexpr int kSketchBlocks = 256;   // one workgroup per CU (12 KB of LDS bucket sums each)
 
 __global__ __launch_bounds__(kLossBlock) void k_sketch_residual(mgs_sketch_residual_args A) {
   extern __shared__ float s_acc[];   // [d][3]: Sf, d/da, d/db
