@@ -154,9 +154,13 @@ constexpr float kLog2eB = 1.4426950408889634f;
 // JONLY (sketch mode only): nothing but the per-pixel pose-Jacobian rows is wanted - the
 // second-order tracking iteration uses grad_sketch_dtau alone (slam_frontend.py:654-669), so
 // the per-splat sums, their reduction and the pair records are skipped altogether.
-template <bool SKETCH, bool JONLY = false>
+// POSE (plain mode only): pose-only backward (tracking: every per-Gaussian gradient pointer is
+// NULL).  dL/dtau needs the mean / conic / depth sums only, so the colour and opacity sums are
+// not formed and six values instead of ten are reduced per splat.
+template <bool SKETCH, bool JONLY = false, bool POSE = false>
 __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
   static_assert(SKETCH || !JONLY, "JONLY is a sketch-mode variant");
+  static_assert(!(SKETCH && POSE), "POSE is a plain-mode variant");
   static_assert(kSeg == 64, "one staged record per lane");
   __shared__ float4 s_r0[kSeg], s_r1[kSeg];
   __shared__ float2 s_r2[kSeg];
@@ -269,8 +273,12 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
   // reduce-scatter bookkeeping (wave_reduce.h): which of the ten sums this lane ends up with
   const unsigned long long b3mask = __ballot((lane & 8) != 0);
   const bool wextra = lane == 31 || lane == 63;
-  const int wofs = wextra ? (lane == 31 ? 8 : 9)
-                          : ((lane & 7) == 0 ? ((lane >> 5) & 1) + 2 * ((lane >> 4) & 1) + 4 * ((lane >> 3) & 1) : -1);
+  // dword of the pair record this lane stores after the reduction (-1: none).  Record layout:
+  // S1 | Sx Sy | Sxx Sxy | Syy | Rr Rg Rb | Rd.  POSE reduces (Sx, Sy, Sxx, Sxy | Syy, Rd) only.
+  const int wofs = POSE ? (wextra ? (lane == 31 ? 5 : 9)
+                                  : ((lane & 15) == 0 ? 1 + ((lane >> 5) & 1) + 2 * ((lane >> 4) & 1) : -1))
+                        : (wextra ? (lane == 31 ? 8 : 9)
+                                  : ((lane & 7) == 0 ? ((lane >> 5) & 1) + 2 * ((lane >> 4) & 1) + 4 * ((lane >> 3) & 1) : -1));
   // Packed operands: the per-quadrant body is written on float2 values so that it maps onto
   // v_pk_{add,mul,fma}_f32 without register shuffles (measured on gfx950: a packed FMA issues
   // in about the time of a scalar one, so pairs of independent FMAs halve their issue cost).
@@ -317,7 +325,12 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
       T[q] *= om;
       const float Wt = k ? ar * dA : 0.f;
       const v2f Wxy = v2f{Wt, Wt} * d;                // (W dx, W dy)
-      if constexpr (!JONLY) {
+      if constexpr (POSE) {
+        R12 += Wxy;
+        R34 = __builtin_elementwise_fma(v2f{Wxy.x, Wxy.x}, d, R34);
+        r5 = __builtin_fmaf(Wxy.y, d.y, r5);
+        r0 = __builtin_fmaf(w, G2d[q].y, r0);          // Rd (r0 is free in this variant)
+      } else if constexpr (!JONLY) {
         r0 += Wt;
         R12 += Wxy;
         R34 = __builtin_elementwise_fma(v2f{Wxy.x, Wxy.x}, d, R34);
@@ -344,8 +357,13 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
       // the ten wave totals land in ten different lanes; each stores its own dword of the
       // pair's record (slot of splat j broadcast from lane j): one store instruction per splat
       float mres, eres;
-      float r[10] = {r0, R12.x, R12.y, R34.x, R34.y, r5, R67.x, R67.y, R89.x, R89.y};
-      wave_sum10_scatter(r, b3mask, mres, eres);
+      if constexpr (POSE) {
+        float r[6] = {R12.x, R12.y, R34.x, R34.y, r5, r0};
+        wave_sum6_scatter(r, mres, eres);
+      } else {
+        float r[10] = {r0, R12.x, R12.y, R34.x, R34.y, r5, R67.x, R67.y, R89.x, R89.y};
+        wave_sum10_scatter(r, b3mask, mres, eres);
+      }
       float* dst = reinterpret_cast<float*>(B.pair_grad) + (size_t)__builtin_amdgcn_readlane(slot, j) * 12;
       if (wofs >= 0) dst[wofs] = wextra ? eres : mres;
       written |= 1ull << j;
@@ -489,6 +507,7 @@ __global__ __launch_bounds__(kPreBlock) void k_preprocess_bwd(KP P, KB B) {
         a[4] += y.x; a[5] += y.y; a[6] += y.z; a[7] += y.w;
         a[8] += z.x; a[9] += z.y;
       }
+      if (!B.g_means3D) { a[0] = 0.f; a[6] = 0.f; a[7] = 0.f; a[8] = 0.f; }   // pose-only: not produced
       // a[] = raw pixel sums (S1, Sx, Sy, Sxx, Sxy, Syy, Rr, Rg, Rb, Rd) over all tiles of
       // the Gaussian; the conic / opacity are per-Gaussian, so the linear map to screen-space
       // gradients is applied once here instead of once per pair
@@ -593,7 +612,10 @@ int launch_backward(const KP& P, const KB& B, hipStream_t st, bool skip_tau_redu
     launch_smem("sketch_bucket", k_sketch_bucket, dim3(kBucketBlocks), dim3(256), nacc * sizeof(float), st, P, B);
     if (B.sketch_only) return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
   } else {
-    launch("blend_bwd", k_blend_bwd<false>, dim3(grid_pad(P.max_segs, kBwdChunk)), dim3(64), st, P, B);
+    if (B.g_means3D)
+      launch("blend_bwd", k_blend_bwd<false>, dim3(grid_pad(P.max_segs, kBwdChunk)), dim3(64), st, P, B);
+    else   // pose-only (tracking)
+      launch("blend_bwd", k_blend_bwd<false, false, true>, dim3(grid_pad(P.max_segs, kBwdChunk)), dim3(64), st, P, B);
   }
   const int npre = (P.N + kPreBlock - 1) / kPreBlock;
   launch("preprocess_bwd", k_preprocess_bwd, dim3(npre), dim3(kPreBlock), st, P, B);

@@ -65,4 +65,43 @@ __device__ __forceinline__ void wave_sum10_scatter(float (&r)[10], unsigned long
   extra = r[8];
 }
 
+// Six wave64 sums (the pose-only backward needs Sx, Sy, Sxx, Sxy, Syy, Rd only): r[0..3] go
+// through one permlane32 and one permlane16 level and a 4-step DPP row reduction, r[4..5]
+// through one permlane32 level and a 5-step DPP reduction.  17 instructions.  On return
+//   main : every lane of 16-lane row R holds the wave total of r[idx],
+//          idx = ((lane >> 5) & 1) + 2 * ((lane >> 4) & 1)            (r[0..3])
+//   extra: lane 31 holds the total of r[4], lane 63 the total of r[5]
+// All 64 lanes must be active.
+__device__ __forceinline__ void wave_sum6_scatter(float (&r)[6], float& main, float& extra) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_permlane32_swap_b32 %0, %1\n\t"
+      "v_permlane32_swap_b32 %2, %3\n\t"
+      "v_permlane32_swap_b32 %4, %5\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32 %0, %0, %1\n\t"
+      "v_add_f32 %2, %2, %3\n\t"
+      "v_add_f32 %4, %4, %5\n\t"
+      "s_nop 1\n\t"
+      "v_permlane16_swap_b32 %0, %2\n\t"
+      "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32 %0, %0, %2\n\t"
+      "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %4, %4 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]));
+  main = r[0];
+  extra = r[4];
+}
+
 }  // namespace mgs
