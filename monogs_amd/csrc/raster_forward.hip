@@ -10,6 +10,8 @@
 //
 // Replaces rasterize_gaussians (forward) of the reference's CUDA extension, called at
 // /root/reference gaussian_splatting/gaussian_renderer/__init__.py:151-168.
+#include <type_traits>
+
 #include "launch.h"
 #include "raster_kernels.h"
 
@@ -649,49 +651,56 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
       // n_touched only counts contributions made while T(1-alpha) > 0.5: once no pixel of the
       // quadrant is that transparent any more the counting code is skipped (wave-uniform)
       const bool count_touch = __builtin_amdgcn_ballot_w64(T > kTouchT && live != 0.f) != 0ull;
-      auto visit = [&](int j, const float4 u, const float4 v, const float2 bd) {
-        const float dx = u.x - fpx, dy = u.y - fpy;
-        const float pw = dx * (u.z * dx + u.w * dy) + v.x * dy * dy;
-        const float araw = v.y * __builtin_amdgcn_exp2f(pw);
-        float a = fminf(kAlphaMax, araw);
-        a = ((pw <= 0.f && a >= kAlphaMin) ? a : 0.f) * live;
-        const float test_T = T - a * T;
-        // T >= kTStop is invariant, so test_T < kTStop implies a > 0: the pixel saturates
-        // here, this splat is NOT blended and nothing after it is.
-        const bool stop = test_T < kTStop;
-        live = stop ? 0.f : live;
-        a = stop ? 0.f : a;
-        const float w = a * T;
-        const v2f ww = {w, w};
-        const v2f rg = {v.z, v.w}, bdv = {bd.x, bd.y};
-        C01 = __builtin_elementwise_fma(rg, ww, C01);
-        C2D = __builtin_elementwise_fma(bdv, ww, C2D);
-        T = stop ? T : test_T;
-        last = a > 0.f ? (base + j + 1) : last;
-        if (count_touch) {
-          const unsigned long long tm = __builtin_amdgcn_ballot_w64(a > 0.f && test_T > kTouchT);
-          if (tm != 0ull) touched += lane == j ? __popcll(tm) : 0;
+      // the walk is instantiated twice (with / without the counting code) so that the choice
+      // costs one branch per segment instead of instructions in every visit
+      auto walk = [&](auto touch_tag) {
+        constexpr bool kTouch = decltype(touch_tag)::value;
+        auto visit = [&](int j, const float4 u, const float4 v, const float2 bd) {
+          const float dx = u.x - fpx, dy = u.y - fpy;
+          const float pw = dx * (u.z * dx + u.w * dy) + v.x * dy * dy;
+          const float araw = v.y * __builtin_amdgcn_exp2f(pw);
+          float a = fminf(kAlphaMax, araw);
+          a = ((pw <= 0.f && a >= kAlphaMin) ? a : 0.f) * live;
+          const float test_T = T - a * T;
+          // T >= kTStop is invariant, so test_T < kTStop implies a > 0: the pixel saturates
+          // here, this splat is NOT blended and nothing after it is.
+          const bool stop = test_T < kTStop;
+          live = stop ? 0.f : live;
+          a = stop ? 0.f : a;
+          const float w = a * T;
+          const v2f ww = {w, w};
+          const v2f rg = {v.z, v.w}, bdv = {bd.x, bd.y};
+          C01 = __builtin_elementwise_fma(rg, ww, C01);
+          C2D = __builtin_elementwise_fma(bdv, ww, C2D);
+          T = stop ? T : test_T;
+          last = a > 0.f ? (base + j + 1) : last;
+          if constexpr (kTouch) {
+            const unsigned long long tm = __builtin_amdgcn_ballot_w64(a > 0.f && test_T > kTouchT);
+            if (tm != 0ull) touched += lane == j ? __popcll(tm) : 0;
+          }
+        };
+        // two-way unrolled walk over the set bits of m: splat j in (u0, v0, w0), the next one
+        // is prefetched into (u1, v1, w1) and vice versa, so no registers are rotated
+        int j0 = __builtin_ctzll(m);
+        float4 u0 = s_rec[3 * j0], v0 = s_rec[3 * j0 + 1];
+        float2 w0 = *reinterpret_cast<const float2*>(&s_rec[3 * j0 + 2]);
+        while (true) {
+          mask_clear_bit(m, j0);
+          const int j1 = __builtin_ctzll(m) & 63;       // m == 0: harmless read of slot 63
+          const float4 u1 = s_rec[3 * j1], v1 = s_rec[3 * j1 + 1];
+          const float2 w1 = *reinterpret_cast<const float2*>(&s_rec[3 * j1 + 2]);
+          visit(j0, u0, v0, w0);
+          if (m == 0ull) break;
+          mask_clear_bit(m, j1);
+          j0 = __builtin_ctzll(m) & 63;
+          u0 = s_rec[3 * j0]; v0 = s_rec[3 * j0 + 1];
+          w0 = *reinterpret_cast<const float2*>(&s_rec[3 * j0 + 2]);
+          visit(j1, u1, v1, w1);
+          if (m == 0ull) break;
         }
       };
-      // two-way unrolled walk over the set bits of m: splat j in (u0, v0, w0), the next one
-      // is prefetched into (u1, v1, w1) and vice versa, so no registers are rotated
-      int j0 = __builtin_ctzll(m);
-      float4 u0 = s_rec[3 * j0], v0 = s_rec[3 * j0 + 1];
-      float2 w0 = *reinterpret_cast<const float2*>(&s_rec[3 * j0 + 2]);
-      while (true) {
-        mask_clear_bit(m, j0);
-        const int j1 = __builtin_ctzll(m) & 63;       // m == 0: harmless read of slot 63
-        const float4 u1 = s_rec[3 * j1], v1 = s_rec[3 * j1 + 1];
-        const float2 w1 = *reinterpret_cast<const float2*>(&s_rec[3 * j1 + 2]);
-        visit(j0, u0, v0, w0);
-        if (m == 0ull) break;
-        mask_clear_bit(m, j1);
-        j0 = __builtin_ctzll(m) & 63;
-        u0 = s_rec[3 * j0]; v0 = s_rec[3 * j0 + 1];
-        w0 = *reinterpret_cast<const float2*>(&s_rec[3 * j0 + 2]);
-        visit(j1, u1, v1, w1);
-        if (m == 0ull) break;
-      }
+      if (count_touch) walk(std::true_type{});
+      else walk(std::false_type{});
     }
     if (touched > 0) atomicAdd(&P.n_touched[cid], touched);
     if (__builtin_amdgcn_ballot_w64(live != 0.f) == 0ull) break;   // quadrant saturated
