@@ -689,12 +689,14 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
           const int j1 = __builtin_ctzll(m) & 63;       // m == 0: harmless read of slot 63
           const float4 u1 = s_rec[3 * j1], v1 = s_rec[3 * j1 + 1];
           const float2 w1 = *reinterpret_cast<const float2*>(&s_rec[3 * j1 + 2]);
+          __builtin_amdgcn_sched_barrier(0);           // keep the prefetch above the arithmetic
           visit(j0, u0, v0, w0);
           if (m == 0ull) break;
           mask_clear_bit(m, j1);
           j0 = __builtin_ctzll(m) & 63;
           u0 = s_rec[3 * j0]; v0 = s_rec[3 * j0 + 1];
           w0 = *reinterpret_cast<const float2*>(&s_rec[3 * j0 + 2]);
+          __builtin_amdgcn_sched_barrier(0);
           visit(j1, u1, v1, w1);
           if (m == 0ull) break;
         }
