@@ -38,6 +38,7 @@ class GaussianRasterizationSettings(NamedTuple):
 # pair-capacity high-water mark per device: the blend stage is launched optimistically
 # with this capacity while the host waits (concurrently) for the true pair count.
 _capacity_hint: dict = {}
+_bwd_scratch: dict = {}
 last_stats: dict = {}
 
 
@@ -208,17 +209,28 @@ class _RasterizeGaussians(torch.autograd.Function):
         shape = _cabi.RasterShape(N, W, H, deg, K, cap, float(st.tanfovx), float(st.tanfovy),
                                   float(st.scale_modifier))
         sizes = _sizes(shape)
+        # one allocation for all gradient outputs (views are handed to autograd, which adopts
+        # them as .grad without copying) and a per-device scratch reused by every backward on
+        # the stream (it is dead once the launch sequence has run)
+        ncol = 3 * K if sh is not None else 3
+        widths = [3, 3, ncol, 1, 3 if sc is not None else 0, 4 if rot is not None else 0,
+                  6 if cov is not None else 0]
+        offs, off = [], 0
+        for w in widths:                      # every part starts on a 256-B boundary (float4 stores)
+            offs.append(off)
+            off += (N * w + 63) // 64 * 64
+        flat = torch.empty(off + 64, dtype=torch.float32, device=dev)
+        parts = [flat[o:o + N * w].view(N, w) if w else None for o, w in zip(offs, widths)]
+        skey = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        ws = _bwd_scratch.get(skey)
+        if ws is None or ws.numel() < int(sizes.bwd_bytes):
+            ws = _bwd_scratch[skey] = torch.empty(int(sizes.bwd_bytes), dtype=torch.uint8, device=dev)
         out = {
-            "bwd_ws": torch.empty(int(sizes.bwd_bytes), dtype=torch.uint8, device=dev),
-            "g_means3D": torch.empty(N, 3, dtype=torch.float32, device=dev),
-            "g_means2D": torch.empty(N, 3, dtype=torch.float32, device=dev),
-            "g_colors": (torch.empty(N, K, 3, dtype=torch.float32, device=dev) if sh is not None
-                         else torch.empty(N, 3, dtype=torch.float32, device=dev)),
-            "g_op": torch.empty(N, dtype=torch.float32, device=dev),
-            "g_sc": torch.empty(N, 3, dtype=torch.float32, device=dev) if sc is not None else None,
-            "g_rot": torch.empty(N, 4, dtype=torch.float32, device=dev) if rot is not None else None,
-            "g_cov": torch.empty(N, 6, dtype=torch.float32, device=dev) if cov is not None else None,
-            "g_tau": torch.empty(6, dtype=torch.float32, device=dev),
+            "bwd_ws": ws,
+            "g_means3D": parts[0], "g_means2D": parts[1],
+            "g_colors": parts[2].view(N, K, 3) if sh is not None else parts[2],
+            "g_op": parts[3].view(N), "g_sc": parts[4], "g_rot": parts[5], "g_cov": parts[6],
+            "g_tau": flat[off:off + 6],
             "sizes": sizes,
         }
         b = _cabi.BackwardArgs()
