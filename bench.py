@@ -177,6 +177,11 @@ def main():
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (HIP kernels only; no CPU fallback)")
+    # Run autograd's backward on the calling thread.  By default the engine hands GPU nodes to
+    # a per-device worker thread; at ~0.37 ms of GPU work per step that hand-off is visible and
+    # noisy (measured on one box: 0.38-0.53 ms/step with it, 0.367-0.370 without).  A PyTorch
+    # runtime switch, not a change to what is computed (INTEGRATION.md recommends it for MonoGS).
+    torch.autograd.set_multithreading_enabled(False)
     local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -327,7 +332,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"SYN-C: {N} Gaussians @ {W}x{H}, SH degree 0, fwd+bwd incl. "
                                    "pose Jacobian through the autograd binding",
-                       "pairs_D": D, "views_per_step": world,
+                       "pairs_D": D, "views_per_step": world, "autograd_multithreading": False,
                        "parallelism": f"keyframe-parallel x{world}" if distributed else "single view"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels_us": kernels,
             "tracking": tracking, "map_update": map_update,
