@@ -1145,3 +1145,37 @@ def test_native_second_order_iteration_matches_python_formulation(built):
         trk.step_second_order()
     assert trk.check_capacity()
     assert (vb.T.cpu() - torch.eye(4)).abs().max().item() < 0.5 * (T0 - torch.eye(4)).abs().max().item()
+
+
+def test_native_tracker_grows_an_undersized_pair_capacity(built):
+    """All kernels clamp to the pair capacity (no out-of-bounds access when D > capacity); the
+    tracker notices lazily, grows its workspaces and then renders completely."""
+    from monogs_amd.gaussian_renderer import render
+    from monogs_amd.pose import SE3_exp
+    from monogs_amd.slam_loops import Pipe
+    from monogs_amd.tracking_native import NativeTracker
+    sc, gauss, view, dev = _loop_fixture()
+    bg = torch.zeros(3, device=dev)
+    with torch.no_grad():
+        target = render(view(1, torch.eye(4)), gauss, Pipe, bg)["render"].clone()
+    vp = view(2, SE3_exp(torch.tensor([0.01, -0.01, 0.005, 0.002, -0.003, 0.001])))
+    vp.original_image = target
+    vp.rgb_pixel_mask_mapping = (target.sum(0) > 0.01).view(1, *target.shape[1:])
+    trk = NativeTracker(vp, gauss, bg, capacity_margin=0.4)       # 40 % of the pairs fit
+    D0 = trk.pairs()
+    assert trk.capacity < D0
+    trk.step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(vp.T).all()
+    trk.capacity_margin = 1.5
+    assert not trk.check_capacity()              # overflow detected, workspaces regrown to 1.5 * D
+    assert trk.capacity >= trk.pairs()
+    trk.step()
+    torch.cuda.synchronize()
+    assert trk.check_capacity()
+    with torch.no_grad():
+        full = render(vp, gauss, Pipe, bg)["render"]
+    # the tracker's last forward rendered the pose BEFORE its final update; render it again natively
+    trk.step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(trk.color).all() and (trk.color - full).abs().mean().item() < 0.05
