@@ -292,6 +292,11 @@ typedef struct mgs_tracking_loss_args {
 int32_t mgs_tracking_loss_partial_count(int64_t num_pixels);
 int32_t mgs_tracking_loss_forward(const mgs_tracking_loss_args* args, void* stream);
 int32_t mgs_tracking_loss_backward(const mgs_tracking_loss_args* args, void* stream);
+/* Forward + backward in two launches (no finish kernels): every workgroup of the backward sums
+ * the forward's block sums itself; scalars[0] = loss; the exposure-gradient block partials are
+ * left at partial[n .. 3n) ([2, n]: d/da then d/db, n = *num_blocks_out) for a consumer that
+ * sums them (mgs_pose_adam_step: exposure_partials).  grad_a / grad_b are not written. */
+int32_t mgs_tracking_loss_fused(const mgs_tracking_loss_args* args, int32_t* num_blocks_out, void* stream);
 
 
 /* ---- native tracking iteration (row a12: utils/slam_frontend.py:493-630) ---------------- */

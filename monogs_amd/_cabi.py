@@ -19,7 +19,7 @@ EXPORTS = (
     "mgs_raster_forward_project", "mgs_raster_forward_blend", "mgs_raster_backward",
     "mgs_knn_scratch_bytes", "mgs_knn_dist2", "mgs_profile_enable", "mgs_profile_read",
     "mgs_pose_adam_step", "mgs_tracking_loss_partial_count", "mgs_tracking_loss_forward",
-    "mgs_tracking_loss_backward", "mgs_lm_solve_step", "mgs_mapping_loss_forward",
+    "mgs_tracking_loss_backward", "mgs_tracking_loss_fused", "mgs_lm_solve_step", "mgs_mapping_loss_forward",
     "mgs_mapping_loss_backward", "mgs_camera_from_pose", "mgs_tracking_iteration",
     "mgs_adam_step_multi", "mgs_map_plan_blocks", "mgs_map_plan_count", "mgs_map_plan_emit",
     "mgs_map_gather", "mgs_pack_mapping_grads", "mgs_sketch_assign", "mgs_sketch_residual",
@@ -165,6 +165,8 @@ def lib():
     L.mgs_adam_step_multi.restype = C.c_int32
     L.mgs_adam_step_multi.argtypes = [C.POINTER(AdamGroup), C.c_int32, C.c_double, C.c_double, C.c_double,
                                       C.c_void_p]
+    L.mgs_tracking_loss_fused.restype = C.c_int32
+    L.mgs_tracking_loss_fused.argtypes = [C.POINTER(TrackingLossArgs), C.POINTER(C.c_int32), C.c_void_p]
     L.mgs_sketch_assign.restype = C.c_int32
     L.mgs_sketch_assign.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p,
                                     C.c_void_p]

@@ -156,8 +156,6 @@ int32_t mgs_raster_forward_blend(const mgs_forward_args* args, void* stream) {
   return launch_forward_blend(P, (hipStream_t)stream);
 }
 
-extern "C" int32_t mgs_internal_track_loss_fused(const mgs_tracking_loss_args* a, int32_t* nblk_out, void* stream);
-
 // skip_tau_reduce: the caller sums tau_partial itself (*tau_partials / *num_partials are set)
 static int32_t raster_backward_impl(const mgs_backward_args* args, void* stream, bool skip_tau_reduce,
                                     const float** tau_partials, int32_t* num_partials,
@@ -225,7 +223,7 @@ int32_t mgs_tracking_iteration(const mgs_tracking_iter_args* args, void* stream)
   L.grad_out = args->one; L.grad_image = args->grad_image;
   L.grad_a = args->grad_exposure; L.grad_b = args->grad_exposure + 1;
   int32_t nblk = 0;
-  if ((rc = mgs_internal_track_loss_fused(&L, &nblk, stream)) != MGS_OK) return rc;
+  if ((rc = mgs_tracking_loss_fused(&L, &nblk, stream)) != MGS_OK) return rc;
   mgs_backward_args B;
   memset(&B, 0, sizeof(B));
   B.fwd = args->fwd;

@@ -606,7 +606,7 @@ int32_t mgs_tracking_loss_partial_count(int64_t num_pixels) { return 3 * loss_bl
 
 // Fused form used by mgs_tracking_iteration: forward sums + backward in two launches; the
 // exposure partials ([2, nblk]) start at partial + nblk.
-int32_t mgs_internal_track_loss_fused(const mgs_tracking_loss_args* a, int32_t* nblk_out, void* stream) {
+int32_t mgs_tracking_loss_fused(const mgs_tracking_loss_args* a, int32_t* nblk_out, void* stream) {
   if (!a || !a->image || !a->opacity || !a->gt || !a->exposure_a || !a->exposure_b || !a->partial ||
       !a->scalars || !a->grad_out || !a->grad_image || a->num_pixels < 1)
     return MGS_ERR_BAD_ARGUMENT;
