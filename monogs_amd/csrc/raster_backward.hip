@@ -227,8 +227,12 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
     unsigned int mask4 = 0;
     if (lane < nb) {
       const unsigned int id = P.pack ? lo >> kPackBits : lo;
-      if constexpr (!JONLY)
+      if constexpr (!JONLY) {
         slot = pair_slot_base(P, (int)id) + (int)(P.pack ? (lo & ((1u << kPackBits) - 1u)) : P.payload[k0 + lane]);
+        // slots are Gaussian-major positions among ALL pairs: with an undersized capacity some
+        // lie beyond the pair_grad buffer (the forward was incomplete anyway) - never touch them
+        if (slot >= P.cap) slot = -1;
+      }
       if (!dead) {
         const float4* src = reinterpret_cast<const float4*>(P.rec + id);
         const float4 qa = src[0], qb = src[1];
@@ -364,8 +368,9 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
         float r[10] = {r0, R12.x, R12.y, R34.x, R34.y, r5, R67.x, R67.y, R89.x, R89.y};
         wave_sum10_scatter(r, b3mask, mres, eres);
       }
-      float* dst = reinterpret_cast<float*>(B.pair_grad) + (size_t)__builtin_amdgcn_readlane(slot, j) * 12;
-      if (wofs >= 0) dst[wofs] = wextra ? eres : mres;
+      const int sj = __builtin_amdgcn_readlane(slot, j);
+      float* dst = reinterpret_cast<float*>(B.pair_grad) + (size_t)max(sj, 0) * 12;
+      if (wofs >= 0 && sj >= 0) dst[wofs] = wextra ? eres : mres;
       written |= 1ull << j;
     }
   }
@@ -499,7 +504,8 @@ __global__ __launch_bounds__(kPreBlock) void k_preprocess_bwd(KP P, KB B) {
     const float p[3] = {P.means[3 * idx], P.means[3 * idx + 1], P.means[3 * idx + 2]};
     if (radius > 0) {
       float a[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      const int s0 = pair_slot_base(P, idx), s1 = s0 + P.pair_count[idx];
+      // clamped to the capacity of the pair_grad buffer (see k_blend_bwd)
+      const int s0 = min(pair_slot_base(P, idx), P.cap), s1 = min(s0 + P.pair_count[idx], P.cap);
       for (int s = s0; s < s1; s++) {
         const float4* src = B.pair_grad + (size_t)s * 3;
         const float4 x = src[0], y = src[1], z = src[2];

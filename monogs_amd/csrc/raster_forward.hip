@@ -502,12 +502,16 @@ __global__ __launch_bounds__(256) void k_tile_sort(KP P) {
   const int tid = threadIdx.x;
   for (int tile = blockIdx.x; tile < P.T; tile += gridDim.x) {
   int start = P.tile_offset[tile], end = P.tile_offset[tile + 1];
+  const int n_all = end - start;                    // as counted by the scans (seg_offset)
   start = min(start, P.cap); end = min(end, P.cap);
   const int n = end - start;
   if (MIN_N == 0) {   // segment -> tile map for the segment-parallel backward
-    const int s0 = P.seg_offset[tile], ns = (n + kSeg - 1) / kSeg;
+    // EVERY segment the scan counted gets a record - also those cut off by an undersized pair
+    // capacity (0 splats), so that the backward never reads an unwritten record
+    const int s0 = P.seg_offset[tile], ns = (n_all + kSeg - 1) / kSeg;
     for (int i = tid; i < ns; i += 256)
-      if (s0 + i < P.max_segs) P.seg_rec[s0 + i] = make_int4(tile, start + i * kSeg, min(kSeg, n - i * kSeg), i * kSeg);
+      if (s0 + i < P.max_segs)
+        P.seg_rec[s0 + i] = make_int4(tile, min(start + i * kSeg, P.cap), max(0, min(kSeg, n - i * kSeg)), i * kSeg);
   }
   if (n <= 1 || n <= MIN_N || (MIN_N == 0 && n > CAP)) continue;   // workgroup-uniform
   unsigned long long* gk = P.keys + start;
