@@ -570,7 +570,7 @@ __device__ __forceinline__ void mask_clear_bit(unsigned long long& m, int j) {
   asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(j));
 }
 
-#ifdef MGS_STAMP   // diagnostic build only (scratch/stamp.py): per-workgroup start/end stamps
+#ifdef MGS_STAMP   // diagnostic build only (profiles/stamp_forward.py): per-workgroup start/end stamps
 __device__ long long g_stamps[4 * 65536];
 extern "C" int mgs_debug_read_stamps(long long* host, int n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(long long) * n);
