@@ -218,8 +218,20 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
     // that (unwritten) state into the arithmetic
     if (last[q] <= base) { T[q] = 0.f; gS[q] = 0.f; }
   }
-  // does any pixel of the tile reach this segment?  (one ballot instead of a shuffle tree)
-  const bool dead = __ballot(max(max(last[0], last[1]), max(last[2], last[3])) > base) == 0ull;
+  // Last list position that still contributes anywhere in each quadrant (wave maxima of
+  // n_contrib).  A splat behind it cannot contribute in that quadrant - the forward had stopped
+  // visiting the saturated quadrant - so its reach bit is dropped at staging time and the
+  // quadrant body is never entered for it.
+  int qlast[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    int v = last[q];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
+    qlast[q] = v;
+  }
+  // does any pixel of the tile reach this segment?
+  const bool dead = max(max(qlast[0], qlast[1]), max(qlast[2], qlast[3])) <= base;
 
   // ---- stage the segment's records (one per lane): slot, raw conic, quadrant reach mask ---
   int slot = -1;
@@ -250,7 +262,7 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           const float x0 = (float)(tx * kTile + 8 * (q & 1)), y0 = (float)(ty * kTile + 8 * (q >> 1));
-          if (x0 <= Wm && y0 <= Hm &&
+          if (base + lane < qlast[q] && x0 <= Wm && y0 <= Hm &&
               box_reachable(qa.x, qa.y, qb.x, qb.y, qb.z, qmax, x0, y0, fminf(x0 + 7.f, Wm), fminf(y0 + 7.f, Hm)))
             mask4 |= 1u << q;
         }
