@@ -382,3 +382,20 @@ def test_synthetic_scene_is_deterministic_and_matches_baseline_spec():
     assert abs(cam.tanfovx - 0.59768) < 1e-4 and abs(cam.tanfovy - 0.44510) < 1e-4
     z = a.means3D[:, 2]
     assert z.min() >= 0.5 and z.max() <= 6.0
+
+
+def test_oracle_reproduces_the_committed_syn_a_vectors():
+    """tests/golden/syn_a_oracle.npz (made by tests/golden/make_syn_golden.py) freezes the
+    oracle on BASELINE config 1's shape: any change to its arithmetic shows up here."""
+    import importlib.util
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_syn_golden", os.path.join(here, "golden", "make_syn_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    got = mod.compute()
+    want = np.load(os.path.join(here, "golden", "syn_a_oracle.npz"))
+    for k in want.files:
+        if want[k].dtype.kind == "i":
+            assert (got[k] != want[k]).sum() <= 2, k          # ceil() of a radius may flip across BLAS builds
+        else:
+            assert np.allclose(got[k], want[k], rtol=1e-4, atol=1e-6), k
