@@ -103,3 +103,49 @@ class FlatGradBucket:
                 dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
                 dist.all_reduce(self.radii, op=dist.ReduceOp.MAX, group=group)
         return self.unpack()
+
+
+def all_gather_visibility(n_touched: torch.Tensor, group=None) -> torch.Tensor:
+    """Occlusion-aware visibility of every view of the window on every rank
+    (utils/slam_backend.py:251-255: `occ_aware_visibility[kf] = n_touched > 0`), needed on prune
+    iterations for `n_obs` (:262-265).  Each rank contributes its own view's mask, bit-packed
+    (N / 8 bytes per view over the wire); returns bool [world, N] in rank order."""
+    vis = n_touched > 0
+    N = int(vis.shape[0])
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return vis[None]
+    world = dist.get_world_size(group)
+    pad = (-N) % 8
+    bits = torch.cat([vis, vis.new_zeros(pad)]) if pad else vis
+    weights = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=vis.device)
+    packed = (bits.view(-1, 8).to(torch.uint8) * weights).sum(dim=1).to(torch.uint8)
+    staged = dist.get_backend(group) == "gloo" and packed.is_cuda      # CPU rehearsal of the exchange
+    send = packed.cpu() if staged else packed
+    out = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(out, send, group=group)
+    allp = torch.stack(out).to(vis.device)
+    unpacked = ((allp[:, :, None] >> torch.arange(8, device=vis.device, dtype=torch.uint8)) & 1).bool()
+    return unpacked.reshape(world, -1)[:, :N]
+
+
+def observation_counts(visibility: torch.Tensor) -> torch.Tensor:
+    """n_obs of slam_backend.py:262-265: in how many views of the window each Gaussian is seen."""
+    return visibility.to(torch.int32).sum(dim=0)
+
+
+def broadcast_split_noise(num_selected: int, device, generator=None, src: int = 0, group=None) -> torch.Tensor:
+    """The random offsets of densify_and_split (gaussian_model.py:608-609) must be identical on
+    every rank or the replicated maps diverge: rank `src` draws the [2 * n_selected, 3] unit
+    normals and broadcasts them (pass the result as `noise=` to map_update.densify_and_prune)."""
+    noise = torch.empty(2 * num_selected, 3, device=device)
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if not distributed or dist.get_rank(group) == src:
+        noise = torch.randn(2 * num_selected, 3, device=device, generator=generator)
+    if distributed:
+        if dist.get_backend(group) == "gloo" and noise.is_cuda:
+            tmp = noise.cpu()
+            dist.broadcast(tmp, src=src, group=group)
+            noise = tmp.to(device)
+        else:
+            dist.broadcast(noise, src=src, group=group)
+    return noise

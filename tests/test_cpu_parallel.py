@@ -37,6 +37,16 @@ def _worker(rank, world, port, ret):
     ok &= torch.allclose(stat, want_stat, atol=1e-5) and torch.equal(denom, want_den)
     ok &= torch.equal(radii, want_rad)
     ok &= not torch.equal(view_pose(0), view_pose(1))
+    # prune iterations: every rank learns every view's occlusion-aware visibility -> n_obs
+    from monogs_amd.parallel import all_gather_visibility, broadcast_split_noise, observation_counts
+    nts = [torch.randint(0, 3, (N,), generator=g, dtype=torch.int32) for _ in range(world)]
+    vis = all_gather_visibility(nts[rank])
+    ok &= vis.shape == (world, N) and all(torch.equal(vis[r], nts[r] > 0) for r in range(world))
+    ok &= torch.equal(observation_counts(vis), sum((t > 0).int() for t in nts))
+    # densify_and_split draws identical offsets on every rank
+    noise = broadcast_split_noise(37, "cpu", generator=torch.Generator().manual_seed(100 + rank))
+    want = torch.randn(74, 3, generator=torch.Generator().manual_seed(100))
+    ok &= torch.equal(noise, want)
     ret[rank] = bool(ok)
     dist.destroy_process_group()
 
