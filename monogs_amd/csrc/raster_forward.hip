@@ -421,12 +421,12 @@ __global__ __launch_bounds__(64 * kColGroups) void k_bin_colsum(KP P, int nblk) 
 // workgroup barrier - LDS operations of one wave execute in order - only the few with
 // larger blocks are bracketed by __syncthreads().  WAVE_LOCAL = false (HBM fallback for
 // oversized tiles) keeps a barrier after every sub-stage.
-template <bool WAVE_LOCAL, bool HAS_VAL, typename KP_, typename VP_>
+template <bool WAVE_LOCAL, bool HAS_VAL, int NWAVES, typename KP_, typename VP_>
 __device__ __forceinline__ void bitonic_sort(KP_ key, VP_ val, int n, int tid) {
   int m = 2;
   while (m < n) m <<= 1;
   const int half_m = m >> 1;
-  const int nw = WAVE_LOCAL ? max(1, min(4, m >> 7)) : 4;     // active waves
+  const int nw = WAVE_LOCAL ? max(1, min(NWAVES, m >> 7)) : NWAVES;     // active waves
   const int chunk = m / nw;                                   // elements owned by a wave
   const int cpw = half_m / nw;                                // comparators per wave
   const int wave = tid >> 6, lane = tid & 63;
@@ -495,8 +495,8 @@ __device__ __forceinline__ void bitonic_sort(KP_ key, VP_ val, int n, int tid) {
 // Two launches by tile size class, so that the common small tiles run at 12 KB of LDS per
 // workgroup (high occupancy) and only crowded tiles pay for 48 KB; tiles beyond 4096 pairs
 // sort in place in HBM with the same network.
-template <int CAP, int MIN_N, bool PACKED>
-__global__ __launch_bounds__(256) void k_tile_sort(KP P) {
+template <int CAP, int MIN_N, bool PACKED, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_tile_sort(KP P) {
   __shared__ unsigned long long s_key[CAP];
   __shared__ unsigned int s_val[PACKED ? 1 : CAP];
   const int tid = threadIdx.x;
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256) void k_tile_sort(KP P) {
     // EVERY segment the scan counted gets a record - also those cut off by an undersized pair
     // capacity (0 splats), so that the backward never reads an unwritten record
     const int s0 = P.seg_offset[tile], ns = (n_all + kSeg - 1) / kSeg;
-    for (int i = tid; i < ns; i += 256)
+    for (int i = tid; i < ns; i += THREADS)
       if (s0 + i < P.max_segs)
         P.seg_rec[s0 + i] = make_int4(tile, min(start + i * kSeg, P.cap), max(0, min(kSeg, n - i * kSeg)), i * kSeg);
   }
@@ -518,17 +518,17 @@ __global__ __launch_bounds__(256) void k_tile_sort(KP P) {
   unsigned int* gv = PACKED ? nullptr : P.payload + start;
   if (n <= CAP) {
     __syncthreads();      // the previous tile of this workgroup is done with the LDS arrays
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += THREADS) {
       s_key[i] = gk[i];
       if constexpr (!PACKED) s_val[i] = gv[i];
     }
-    bitonic_sort<true, !PACKED>(s_key, s_val, n, tid);
-    for (int i = tid; i < n; i += 256) {
+    bitonic_sort<true, !PACKED, THREADS / 64>(s_key, s_val, n, tid);
+    for (int i = tid; i < n; i += THREADS) {
       gk[i] = s_key[i];
       if constexpr (!PACKED) gv[i] = s_val[i];
     }
   } else {
-    bitonic_sort<false, !PACKED>(gk, gv, n, tid);
+    bitonic_sort<false, !PACKED, THREADS / 64>(gk, gv, n, tid);
   }
   }
 }
@@ -783,12 +783,14 @@ int launch_forward_blend(const KP& P, hipStream_t st) {
     launch("bin_emit", k_bin, dim3((P.N + 255) / 256), dim3(256), st, P, 1);
   }
   // crowded tiles are rare: for them a small grid walks the tile list instead of T mostly idle workgroups
+  // (crowded tiles get 1024 threads: 16 waves on the 4096-key network - 170 -> ~35 us when every
+  // tile of a 320x240 view holds ~2500 splats)
   if (P.pack) {
-    launch("tile_sort", k_tile_sort<1024, 0, true>, dim3(P.T), dim3(256), st, P);
-    launch("tile_sort_big", k_tile_sort<4096, 1024, true>, dim3(min(P.T, 256)), dim3(256), st, P);
+    launch("tile_sort", k_tile_sort<1024, 0, true, 256>, dim3(P.T), dim3(256), st, P);
+    launch("tile_sort_big", k_tile_sort<4096, 1024, true, 1024>, dim3(min(P.T, 512)), dim3(1024), st, P);
   } else {
-    launch("tile_sort", k_tile_sort<1024, 0, false>, dim3(P.T), dim3(256), st, P);
-    launch("tile_sort_big", k_tile_sort<4096, 1024, false>, dim3(min(P.T, 256)), dim3(256), st, P);
+    launch("tile_sort", k_tile_sort<1024, 0, false, 256>, dim3(P.T), dim3(256), st, P);
+    launch("tile_sort_big", k_tile_sort<4096, 1024, false, 1024>, dim3(min(P.T, 512)), dim3(1024), st, P);
   }
   launch("blend_fwd", k_blend_fwd, dim3(grid_pad(4 * P.T, kFwdChunk)), dim3(64), st, P);
   return check_launch();
