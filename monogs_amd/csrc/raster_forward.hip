@@ -471,7 +471,46 @@ __device__ __forceinline__ void bitonic_sort(KP_ key, VP_ val, int n, int tid) {
       }
     }
   };
-  for (int k = 2; k <= m; k <<= 1) {
+  // Register-resident sub-stages: a thread loads four consecutive elements (32 B, conflict-free
+  // wide LDS reads) and runs the compare-exchanges at distance 2 and 1 - or the whole k = 2 and
+  // k = 4 rounds - in registers: one LDS round trip instead of two or three, and none of the
+  // 2-way bank conflicts the short-distance stages have.  Elements beyond n are virtual +inf.
+  auto reg_pass = [&](bool first_rounds) {
+    constexpr unsigned long long kInf = ~0ull;
+    for (int e0 = 4 * lane; e0 < chunk; e0 += 256) {
+      const int b0 = wave * chunk + e0;
+      if (b0 >= n) continue;
+      unsigned long long k4[4];
+      unsigned int v4[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        k4[i] = b0 + i < n ? key[b0 + i] : kInf;
+        if constexpr (HAS_VAL) v4[i] = b0 + i < n ? val[b0 + i] : 0u;
+      }
+      auto ce = [&](int a, int b) {
+        if (k4[a] > k4[b]) {
+          const unsigned long long t = k4[a]; k4[a] = k4[b]; k4[b] = t;
+          if constexpr (HAS_VAL) { const unsigned int u = v4[a]; v4[a] = v4[b]; v4[b] = u; }
+        }
+      };
+      if (first_rounds) { ce(0, 1); ce(2, 3); ce(0, 3); ce(1, 2); ce(0, 1); ce(2, 3); }
+      else { ce(0, 2); ce(1, 3); ce(0, 1); ce(2, 3); }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        if (b0 + i < n) {
+          key[b0 + i] = k4[i];
+          if constexpr (HAS_VAL) val[b0 + i] = v4[i];
+        }
+      }
+    }
+  };
+  int k = 2;
+  if (m >= 4) {        // rounds k = 2 and k = 4
+    sync(4 > chunk);
+    if (active) reg_pass(true);
+    k = 8;
+  }
+  for (; k <= m; k <<= 1) {
     {
       sync(k > chunk);
       const int half = k >> 1;
@@ -481,12 +520,16 @@ __device__ __forceinline__ void bitonic_sort(KP_ key, VP_ val, int n, int tid) {
           lo = blk * k + off; hi = blk * k + k - 1 - off;
         });
     }
-    for (int j = k >> 2; j > 0; j >>= 1) {
+    for (int j = k >> 2; j >= 4; j >>= 1) {
       sync(2 * j > chunk);
       if (active)
         run([&](int i, int& lo, int& hi) {
           lo = 2 * i - (i & (j - 1)); hi = lo + j;
         });
+    }
+    if (k >= 8) {      // distances 2 and 1
+      sync(4 > chunk);
+      if (active) reg_pass(false);
     }
   }
   __syncthreads();
