@@ -164,7 +164,7 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
   static_assert(kSeg == 64, "one staged record per lane");
   __shared__ float4 s_r0[kSeg], s_r1[kSeg];
   __shared__ float2 s_r2[kSeg];
-  __shared__ unsigned int s_mask[kSeg];
+  __shared__ unsigned char s_mask[kSeg];   // 4-bit quadrant reach masks (2624 B of LDS in all: 24 waves per CU)
   __shared__ float4 s_coef[SKETCH ? kSeg : 1][9];   // per splat: 6 features x 6 tau components
   const int item = xcd_remap<kBwdChunk>(blockIdx.x), lane = threadIdx.x;
   if (item >= min(P.seg_offset[P.T], P.max_segs)) return;
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
         }
       }
     }
-    s_mask[lane] = mask4;
+    s_mask[lane] = (unsigned char)mask4;
   }
   if (dead) {
     if (!JONLY && slot >= 0) {
