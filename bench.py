@@ -2,45 +2,84 @@
 """Benchmark of the hot path: rasteriser forward+backward (incl. pose Jacobian) on the
 SYN-C workload of BASELINE.md §4 (640x480, 300k Gaussians, SH degree 0).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload synC|replica]
 
 N = 1: one view per step through the autograd binding (what MonoGS's render() +
-loss.backward() exercises).  N > 1 (launched by torch.distributed.run, one rank per
-GPU): keyframe-parallel mapping - Gaussians replicated, one view per rank,
-one RCCL all-reduce(sum) of the flat Gaussian-gradient buffer per step; value = views/s
-over all ranks ("weak" scaling: per-GPU work fixed).
+loss.backward() exercises).
 
-Rank 0 prints ONE JSON line (contract in the task statement) with `roofline`
-(dominant kernel, HIP-event timed inside the library on the launch stream) and
-`cpu_baseline` (C++ host emulation on the host cores, N = 1 only).
+N > 1: keyframe-parallel mapping - Gaussians replicated, one view per rank,
+one all-reduce(sum) of the flat Gaussian-gradient buffer + one all-reduce(max) of the radii
+per step; value = views/s over all ranks ("weak" scaling: per-GPU work fixed).  Launched
+either by the driver (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N
+...`: RANK / LOCAL_RANK / WORLD_SIZE come from the environment) or directly
+(`python bench.py --gpus N`): with WORLD_SIZE unset this process starts the N ranks itself
+as a CHILD `torch.distributed.run` BEFORE touching the GPU and exits with the child's code.
+Backend: "nccl" (= RCCL) when the node has >= N GPUs, otherwise a gloo rehearsal in which the
+ranks share the GPU(s) and the flat buffer is staged through host memory (functional check of
+the exchange on a 1-GPU box; not a performance number - the JSON says which one ran).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant
+kernel, HIP-event timed inside the library on the launch stream) and `cpu_baseline`
+(N = 1 only).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
+WORKLOADS = {
+    # name: (width, height, intrinsics or None = fr3_office scaled, description)
+    "synC": (640, 480, None, "SYN-C"),
+    "replica": (1200, 680, (600.0, 600.0, 599.5, 339.5), "Replica-sized (office0 calibration)"),
+}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="synC")
     ap.add_argument("--gaussians", type=int, default=300_000)
-    ap.add_argument("--width", type=int, default=640)
-    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--no-tracking", action="store_true")
     ap.add_argument("--tracking-iters", type=int, default=100)
-    return ap.parse_args()
+    ap.add_argument("--no-mapping", action="store_true")
+    ap.add_argument("--no-slam", action="store_true")
+    ap.add_argument("--sustain-seconds", type=float, default=2.0)
+    ap.add_argument("--lean", action="store_true",
+                    help="headline + roofline only (for rocprofv3 runs): no cpu baseline, tracking, "
+                         "mapping, SLAM or sustained legs")
+    args = ap.parse_args(argv)
+    if args.lean:
+        args.no_cpu_baseline = args.no_tracking = args.no_mapping = args.no_slam = True
+        args.sustain_seconds = 0.0
+    return args
+
+
+def spawn_ranks(args, argv):
+    """`bench.py --gpus N` without a launcher: start N ranks as a child torch.distributed.run.
+    Nothing in THIS process has initialised the GPU (no torch.cuda call so far), and the program
+    is not replaced (no exec): the child is waited for and its exit code returned."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
 
 
 def bench_tracking(sc, dev, iters):
@@ -51,6 +90,7 @@ def bench_tracking(sc, dev, iters):
     configs/mono/tum/base_config.yaml:256-260).  fr3_office itself is not available offline;
     intrinsics and image size are fr3_office's."""
     import math
+    import torch
     from monogs_amd.gaussian_renderer import render
     from monogs_amd.pose import SE3_exp
     from monogs_amd.slam_loops import (GaussianParams, Pipe, ViewCamera, make_pose_optimizer,
@@ -119,6 +159,7 @@ def bench_map_update(sc, dev):
     """Map maintenance on the SYN-C map: the Gaussian optimiser step
     (fused HIP launch vs torch.optim.Adam, gaussian_model.py:285) and one densify_and_prune
     (gaussian_model.py:674-691) through the plan + gather kernels."""
+    import torch
     import torch.nn as nn
     from monogs_amd.map_update import FusedGaussianAdam, densify_and_prune
     N = sc.means3D.shape[0]
@@ -169,29 +210,44 @@ def bench_map_update(sc, dev):
     return out
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and (args.gpus or 1) > 1:
+        # no launcher: become the launcher (before any GPU call in this process)
+        raise SystemExit(spawn_ranks(args, argv))
+    world = int(env_world or "1")
+    if args.gpus is not None and args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with "
+                         f"--nproc-per-node {args.gpus} (or drop the launcher: bench.py starts the ranks itself)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (HIP kernels only; no CPU fallback)")
     # Run autograd's backward on the calling thread.  By default the engine hands GPU nodes to
     # a per-device worker thread; at ~0.37 ms of GPU work per step that hand-off is visible and
     # noisy (measured on one box: 0.38-0.53 ms/step with it, 0.367-0.370 without).  A PyTorch
-    # runtime switch, not a change to what is computed (INTEGRATION.md recommends it for MonoGS).
+    # runtime switch, not a change to what is computed (INTEGRATION.md recommends it for MonoGS);
+    # the default-engine figure is reported next to it (`default_autograd_engine_fps`).
     torch.autograd.set_multithreading_enabled(False)
-    local_rank = local_rank % max(1, torch.cuda.device_count())
+    ndev = max(1, torch.cuda.device_count())
+    shared_gpu = distributed and ndev < world
+    local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = None
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("MGS_DIST_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm
+        # "nccl" IS RCCL on ROCm; it needs one GPU per rank
+        backend = os.environ.get("MGS_DIST_BACKEND", "gloo" if shared_gpu else "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:   # functional rehearsal only (e.g. 2 ranks sharing one GPU with gloo)
+        else:   # functional rehearsal only (ranks sharing a GPU, buffers staged through the host)
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     import __graft_entry__ as entry
@@ -201,10 +257,13 @@ def main():
     from monogs_amd.parallel import FlatGradBucket, view_pose
     from monogs_amd.tracking_fused import l1_image_depth_loss
 
-    N, W, H = args.gaussians, args.width, args.height
-    sc = S.make_scene(N, W, H, seed=0)
+    wW, wH, intr, wname = WORKLOADS[args.workload]
+    N, W, H = args.gaussians, args.width or wW, args.height or wH
+    if (W, H) != (wW, wH):
+        intr = None
+    sc = S.make_scene(N, W, H, seed=0, intrinsics=intr)
     # every rank renders its own view of the same (replicated) map
-    cam = S.make_camera(W, H, view_pose(rank)) if distributed else sc.cam
+    cam = S.make_camera(W, H, view_pose(rank), intrinsics=intr) if distributed else sc.cam
     m, s, r, o, sh = S.activated(sc)
     params = [t.to(dev).requires_grad_() for t in (m, s, r, o, sh)]
     theta = torch.zeros(3, device=dev, requires_grad=True)
@@ -217,8 +276,9 @@ def main():
     ras = R.GaussianRasterizer(st)
     gt_img, gt_dep = sc.gt_image.to(dev), sc.gt_depth.to(dev)
     bucket = FlatGradBucket(params) if distributed else None
+    ex_events = []
 
-    def step(exchange=True):
+    def step(exchange=True, timed_exchange=False):
         for p in params:
             p.grad = None
         theta.grad = None
@@ -231,7 +291,13 @@ def main():
         loss = l1_image_depth_loss(img, dep, gt_img, gt_dep, 0.05)
         loss.backward()
         if bucket is not None and exchange:
-            bucket.all_reduce(m2d.grad, radii)
+            if timed_exchange:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            bucket.all_reduce(m2d.grad, radii)     # pack (1 launch) + all-reduce(sum) + all-reduce(max)
+            if timed_exchange:
+                e1.record()
+                ex_events.append((e0, e1))
         return loss
 
     def barrier():
@@ -239,22 +305,51 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(k, **kw):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step(**kw)
+        barrier()
+        return time.perf_counter() - t0
+
+    def max_over_ranks(x):
+        if not distributed:
+            return float(x)
+        t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     for _ in range(args.warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if distributed:
-        tmax = torch.tensor([dt], dtype=torch.float64,
-                            device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt = max_over_ranks(timed(args.steps))
     ms_per_step = dt / args.steps * 1e3
     value = world * args.steps / dt          # views (frames) per second, whole job
     D = int(R.last_stats["pairs"])
+
+    # ---- multi-rank extras: exchange cost and per-rank compute, measured separately ----
+    multi = None
+    if distributed:
+        k = min(args.steps, 50)
+        t_compute = timed(k, exchange=False) / k * 1e3           # this rank's fwd+loss+bwd alone
+        timed(k, timed_exchange=True)
+        ex_ms = sum(a.elapsed_time(b) for a, b in ex_events) / max(1, len(ex_events))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {"rank": rank, "compute_ms": round(t_compute, 4),
+                                          "exchange_ms": round(ex_ms, 4), "pairs_D": D,
+                                          "device": torch.cuda.get_device_name(dev)})
+        flat_bytes = bucket.flat.numel() * 4 + bucket.radii.numel() * 4
+        backend_name = "rccl" if backend == "nccl" else backend
+        if shared_gpu:
+            backend_name += " (host-staged rehearsal, ranks share a GPU: not a performance number)"
+        multi = {"backend": backend_name,
+                 "exchange_ms": round(max(g["exchange_ms"] for g in gathered), 4),
+                 "compute_ms_per_rank": [g["compute_ms"] for g in gathered],
+                 "exchange_ms_per_rank": [g["exchange_ms"] for g in gathered],
+                 "pairs_D_per_rank": [g["pairs_D"] for g in gathered],
+                 "exchange_bytes": flat_bytes,
+                 "exchange": "1 pack launch + all_reduce(sum) of the flat fp32 gradient+statistics buffer "
+                             "+ all_reduce(max) of int32 radii"}
 
     # ---- per-kernel timing (separate pass; events slow the stream down slightly) ----
     roofline = None
@@ -281,17 +376,38 @@ def main():
         }
         dom = max((k for k in kernels if k in alg), key=lambda k: kernels[k])
         achieved = alg[dom] / (kernels[dom] * 1e-6) / 1e9
-        # HBM traffic per launch from the committed PMC pass (rocprofv3 cannot run inside
-        # this process); only valid for the default workload it was collected on
+        # HBM traffic per launch from the committed PMC pass of THIS round's kernels (rocprofv3
+        # cannot run inside this process; profiles/collect.sh regenerates the file); only valid
+        # for the default workload it was collected on
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if (N, W, H) == (300_000, 640, 480) and os.path.exists(tpath):
             traffic = json.load(open(tpath))["bytes_per_launch"].get(dom)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0,
                     "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                     "algorithmic_bytes": alg[dom], "avg_us": kernels[dom]}
 
-    # ---- CPU baseline: the C++ host emulation on the host cores (rank 0, N = 1) ----
+    # ---- single-GPU extras: sustained rate and the default autograd engine ----
+    extras = {}
+    if rank == 0 and not distributed and args.sustain_seconds > 0:
+        k, t_run = 0, 0.0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        while t_run < args.sustain_seconds:
+            for _ in range(100):
+                step()
+            torch.cuda.synchronize()
+            k += 100
+            t_run = time.perf_counter() - t0
+        extras["sustained_fps"] = {"value": round(k / t_run, 1), "seconds": round(t_run, 2), "steps": k}
+        torch.autograd.set_multithreading_enabled(True)
+        for _ in range(10):
+            step()
+        extras["default_autograd_engine_fps"] = round(args.steps / timed(args.steps), 1)
+        torch.autograd.set_multithreading_enabled(False)
+
+    # ---- CPU baseline (rank 0, N = 1): (a) the C++ host emulation on the same workload on the
+    # host cores, (b) BASELINE.md §3's row: the fp32 PyTorch oracle on SYN-A (5k @ 160x120) ----
     cpu_baseline = None
     if rank == 0 and not distributed and not args.no_cpu_baseline:
         from oracle import torch_raster as O
@@ -310,18 +426,47 @@ def main():
             reps += 1
         cpu_baseline = {"value": round(reps / t_cpu, 3), "unit": "frames/s",
                         "cores": em.num_threads(), "kind": "port",
-                        "sample": f"{reps} fwd+bwd of the same SYN-C workload "
+                        "sample": f"{reps} fwd+bwd of the same workload "
                                   f"({N} Gaussians @ {W}x{H}), OpenMP C++ host emulation "
                                   "(oracle/host_emul.cpp)"}
+        sa = S.make_scene(5000, 160, 120, seed=0)
+        ma, sa_s, ra, oa, sha = S.activated(sa)
+        ca = sa.cam
+        st_a = O.RasterSettings(ca.H, ca.W, ca.tanfovx, ca.tanfovy, sa.bg, 1.0, ca.viewmatrix, ca.projmatrix,
+                                ca.projmatrix_raw, 0, ca.viewmatrix, False, False)
+        times = []
+        for i in range(6):      # 1 warm-up + 5 timed
+            L = [t.clone().requires_grad_() for t in (ma, sa_s, ra, oa, sha)]
+            th_c, rh_c = torch.zeros(3, requires_grad=True), torch.zeros(3, requires_grad=True)
+            t1 = time.perf_counter()
+            oi, _, od, _, _, _ = O.rasterize(L[0], None, L[4], None, L[3], L[1], L[2], None, st_a, th_c, rh_c)
+            S.synthetic_loss(oi, od, sa).backward()
+            times.append(time.perf_counter() - t1)
+        med = sorted(times[1:])[2]
+        cpu_baseline["torch_oracle_syn_a"] = {
+            "value": round(1.0 / med, 3), "unit": "frames/s", "cores": torch.get_num_threads(),
+            "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": "median of 5 fwd+bwd (autograd) of the fp32 PyTorch oracle on SYN-A "
+                      "(5000 Gaussians @ 160x120, BASELINE config 1), 1 warm-up"}
 
     # ---- tracking iterations/s on a frozen synthetic map (second BASELINE metric) ----
-    tracking = None
-    if rank == 0 and not distributed and not args.no_tracking:
+    tracking = map_update = mapping = slam = None
+    single = rank == 0 and not distributed and (N, W, H) == (300_000, 640, 480)
+    if single and not args.no_tracking:
         tracking = bench_tracking(sc, dev, args.tracking_iters)
-
-    map_update = None
-    if rank == 0 and not distributed and not args.no_tracking:
         map_update = bench_map_update(sc, dev)
+    if single and not args.no_mapping:
+        try:
+            from monogs_amd.bench_legs import bench_mapping
+            mapping = bench_mapping(sc, dev)
+        except ImportError:
+            mapping = None
+    if single and not args.no_slam:
+        try:
+            from monogs_amd.bench_legs import bench_slam_surrogate
+            slam = bench_slam_surrogate(dev)
+        except ImportError:
+            slam = None
 
     if rank == 0:
         out = {
@@ -330,14 +475,20 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"SYN-C: {N} Gaussians @ {W}x{H}, SH degree 0, fwd+bwd incl. "
+            "config": {"workload": f"{wname}: {N} Gaussians @ {W}x{H}, SH degree 0, fwd+bwd incl. "
                                    "pose Jacobian through the autograd binding",
                        "pairs_D": D, "views_per_step": world, "autograd_multithreading": False,
                        "parallelism": f"keyframe-parallel x{world}" if distributed else "single view"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels_us": kernels,
-            "tracking": tracking, "map_update": map_update,
         }
-        print(json.dumps(out))
+        if multi is not None:
+            out["multi_gpu"] = multi
+            out["exchange_ms"] = multi["exchange_ms"]
+        out.update(extras)
+        for k, v in (("tracking", tracking), ("map_update", map_update), ("mapping", mapping), ("slam", slam)):
+            if v is not None:
+                out[k] = v
+        print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()      # rank 0 has finished its (collective-free) profiling pass
         dist.destroy_process_group()
@@ -349,6 +500,8 @@ if __name__ == "__main__":
     faulthandler.enable()
     try:
         main()
+    except SystemExit:
+        raise
     except BaseException:
         sys.stderr.write(f"[rank {os.environ.get('RANK', '0')}] bench.py failed:\n{traceback.format_exc()}\n")
         sys.stderr.flush()

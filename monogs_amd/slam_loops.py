@@ -237,28 +237,44 @@ def tracking_step_second_order(viewpoint, gaussians, background, lambda_, repeat
 
 def mapping_step(window: List[ViewCamera], gaussians, gaussian_optimizer, keyframe_optimizer,
                  background, pipe=Pipe, config=DEFAULT_CONFIG, pose_window=3, bucket=None,
-                 fused_loss=False):
+                 fused_loss=False, window_indices: Optional[List[int]] = None, render_fn=None):
     """One mapping iteration over the keyframe window (slam_backend.py:171-332): render
     every view, sum the mapping losses (+ isotropic-scale regulariser), ONE backward, the
     densification statistics, optimiser steps and update_pose of the first pose_window
-    keyframes.  With `bucket` (monogs_amd.parallel.FlatGradBucket) the window is the LOCAL
-    shard of views and gradients/statistics are all-reduced before the optimiser step."""
+    keyframes.
+
+    Keyframe-parallel form: with `bucket` (monogs_amd.parallel.FlatGradBucket)
+    `window` is the LOCAL shard of the views, `window_indices` their positions in the global
+    window (default: rank, rank + world, ...), and gradients / statistics are all-reduced before
+    the optimiser step.  The view-independent regulariser (slam_backend.py:244-246) is added on
+    rank 0 only - the all-reduce SUMS the ranks' gradients, so adding it everywhere would count
+    it world-size times - and the update_pose gate (:328-332) uses the GLOBAL window position."""
+    rank, world = 0, 1
+    if bucket is not None:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            rank, world = dist.get_rank(), dist.get_world_size()
+    if window_indices is None:
+        window_indices = [rank + world * i for i in range(len(window))] if bucket is not None else list(range(len(window)))
+    render_fn = render if render_fn is None else render_fn
     loss = 0.0
     pkgs = []
     for vp in window:
-        pkg = render(vp, gaussians, pipe, background)
+        pkg = render_fn(vp, gaussians, pipe, background)
         if fused_loss:
             from .tracking_fused import mapping_loss
             loss = loss + mapping_loss(config, pkg["render"], pkg["depth"], vp)
         else:
             loss = loss + get_loss_mapping(config, pkg["render"], pkg["depth"], vp, pkg["opacity"])
         pkgs.append(pkg)
-    scaling = gaussians.get_scaling
-    loss = loss + 10 * torch.abs(scaling - scaling.mean(dim=1, keepdim=True)).mean()
+    if rank == 0:
+        scaling = gaussians.get_scaling
+        loss = loss + 10 * torch.abs(scaling - scaling.mean(dim=1, keepdim=True)).mean()
     gaussian_optimizer.zero_grad(set_to_none=True)
     if keyframe_optimizer is not None:
         keyframe_optimizer.zero_grad(set_to_none=True)
-    loss.backward()
+    if torch.is_tensor(loss):
+        loss.backward()
     with torch.no_grad():
         N = gaussians.get_xyz.shape[0]
         grad_norm = torch.zeros(N, device=gaussians.get_xyz.device)
@@ -269,13 +285,17 @@ def mapping_step(window: List[ViewCamera], gaussians, gaussian_optimizer, keyfra
             g2 = torch.linalg.norm(pkg["viewspace_points"].grad[:, :2], dim=-1)
             grad_norm += torch.where(vis, g2, torch.zeros_like(g2))
             denom += vis.float()
-            max_radii = torch.maximum(max_radii, pkg["radii"])
+            max_radii = torch.maximum(max_radii, pkg["radii"].to(torch.int32))
         if bucket is not None:
+            for p in bucket.params:            # a rank without views still takes part in the sum
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
             grad_norm, denom, max_radii = bucket.all_reduce_stats(grad_norm, denom, max_radii)
         gaussian_optimizer.step()
         if keyframe_optimizer is not None:
             keyframe_optimizer.step()
-        for vp in window[:pose_window]:
-            if vp.uid != 0:
+        for vp, gi in zip(window, window_indices):
+            if gi < pose_window and vp.uid != 0:
                 update_pose(vp)
-    return loss.detach(), grad_norm, denom, max_radii
+    loss = loss.detach() if torch.is_tensor(loss) else torch.zeros(())
+    return loss, grad_norm, denom, max_radii

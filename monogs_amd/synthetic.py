@@ -49,9 +49,18 @@ class Camera(NamedTuple):
     projmatrix_raw: torch.Tensor   # P^T           (slam_frontend.py:1815-1825)
 
 
-def make_camera(W=640, H=480, T_w2c: torch.Tensor | None = None) -> Camera:
-    s = W / 640.0
-    fx, fy, cx, cy = 535.4 * s, 539.2 * s, 320.1 * s, 247.6 * s
+# Replica calibration (configs/rgbd/replica/base_config.yaml:17-30): 1200x680
+REPLICA_INTRINSICS = (600.0, 600.0, 599.5, 339.5)
+
+
+def make_camera(W=640, H=480, T_w2c: torch.Tensor | None = None, intrinsics=None) -> Camera:
+    """`intrinsics` = (fx, fy, cx, cy) in pixels of a W x H image; default: fr3_office's,
+    scaled with the image width."""
+    if intrinsics is None:
+        s = W / 640.0
+        fx, fy, cx, cy = 535.4 * s, 539.2 * s, 320.1 * s, 247.6 * s
+    else:
+        fx, fy, cx, cy = (float(v) for v in intrinsics)
     fovx = 2 * math.atan(W / (2 * fx))
     fovy = 2 * math.atan(H / (2 * fy))
     P = projection_matrix2(0.01, 100.0, cx, cy, fx, fy, W, H).t().contiguous()
@@ -73,9 +82,9 @@ class Scene(NamedTuple):
     bg: torch.Tensor         # [3]
 
 
-def make_scene(N: int, W: int = 640, H: int = 480, seed: int = 0) -> Scene:
+def make_scene(N: int, W: int = 640, H: int = 480, seed: int = 0, intrinsics=None) -> Scene:
     g = torch.Generator().manual_seed(seed)
-    cam = make_camera(W, H)
+    cam = make_camera(W, H, intrinsics=intrinsics)
 
     def U(*shape):
         return torch.rand(*shape, generator=g)

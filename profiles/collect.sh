@@ -12,7 +12,7 @@ out=$root/gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 cd "$root"
-BENCH="python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --profile-steps 0 --no-tracking"
+BENCH="python3 bench.py --steps 30 --warmup 5 --lean --profile-steps 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o run -- $BENCH > "$out/stats.log" 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$out/fetch" -o run -- $BENCH > "$out/fetch.log" 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$out/write" -o run -- $BENCH > "$out/write.log" 2>&1

@@ -70,3 +70,109 @@ def test_flat_gradient_bucket_single_process_roundtrip():
     stat, denom, radii = b.all_reduce(torch.ones(10, 3), torch.arange(10, dtype=torch.int32))
     assert all(torch.equal(p.grad, r) for p, r in zip(params, ref))
     assert torch.allclose(stat[1:], torch.full((9,), 2 ** 0.5)) and stat[0] == 0 and denom.sum() == 9 and radii.max() == 9
+
+
+# ---------------------------------------------------------------------------------------------
+# Sharded mapping_step == single-process mapping_step over the full window.  The HIP
+# rasteriser cannot run here, so render() is replaced by an oracle-backed stand-in (tests may
+# use the oracle); what is under test is the host logic: which rank adds the regulariser, the
+# all-reduce of gradients + statistics, and the global-window-index gate of update_pose.
+def _oracle_render(view, pc, pipe, bg, **_):
+    from oracle import torch_raster as O
+    import math
+    st = O.RasterSettings(view.image_height, view.image_width, math.tan(0.5 * view.FoVx), math.tan(0.5 * view.FoVy),
+                          bg, 1.0, view.world_view_transform, view.full_proj_transform, view.projection_matrix,
+                          0, view.camera_center, False, False)
+    m2d = torch.zeros_like(pc.get_xyz, requires_grad=True)
+    img, radii, dep, opa, nt, _ = O.rasterize(pc.get_xyz, m2d, pc.get_features, None, pc.get_opacity,
+                                              pc.get_scaling, pc.get_rotation, None, st,
+                                              view.cam_rot_delta, view.cam_trans_delta)
+    return {"render": img, "viewspace_points": m2d, "visibility_filter": radii > 0, "radii": radii,
+            "depth": dep, "opacity": opa, "n_touched": nt}
+
+
+def _mapping_fixture():
+    import math
+    from monogs_amd import synthetic as S
+    from monogs_amd.parallel import view_pose
+    from monogs_amd.slam_loops import GaussianParams, ViewCamera
+    W, H, N = 48, 32, 300
+    sc = S.make_scene(N, W, H, seed=5)
+    cam = sc.cam
+    fovx, fovy = 2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy)
+    gauss = GaussianParams(sc.means3D, sc.log_scales, sc.rot, sc.opacity_logit, sc.features_dc)
+    g = torch.Generator().manual_seed(9)
+    views = []
+    for i in range(4):
+        img = torch.rand(3, H, W, generator=g)
+        v = ViewCamera(i, img, view_pose(i), cam.projmatrix_raw, fovx, fovy, H, W, "cpu")
+        with torch.no_grad():
+            v.exposure_a.fill_(1.0 + 0.05 * i)
+            v.exposure_b.fill_(0.01 * i)
+        views.append(v)
+    return gauss, views
+
+
+def _optimizers(gauss, views):
+    gopt = torch.optim.Adam([{"params": [gauss._xyz], "lr": 1e-3}, {"params": [gauss._features_dc], "lr": 2e-3},
+                             {"params": [gauss._opacity], "lr": 5e-2}, {"params": [gauss._scaling], "lr": 1e-3},
+                             {"params": [gauss._rotation], "lr": 1e-3}], eps=1e-15)
+    groups = []
+    for v in views:
+        groups += [{"params": [v.cam_rot_delta], "lr": 3e-3}, {"params": [v.cam_trans_delta], "lr": 1e-3},
+                   {"params": [v.exposure_a], "lr": 1e-2}, {"params": [v.exposure_b], "lr": 1e-2}]
+    return gopt, torch.optim.Adam(groups)
+
+
+def _run_mapping(gauss, views, indices, bucket, iters=2):
+    from monogs_amd.slam_loops import mapping_step
+    gopt, kopt = _optimizers(gauss, views)
+    out = None
+    for _ in range(iters):
+        out = mapping_step(views, gauss, gopt, kopt, torch.zeros(3), pose_window=3, bucket=bucket,
+                           window_indices=indices, render_fn=_oracle_render)
+    state = {"xyz": gauss._xyz.detach().clone(), "scaling": gauss._scaling.detach().clone(),
+             "opacity": gauss._opacity.detach().clone(), "rot": gauss._rotation.detach().clone(),
+             "fdc": gauss._features_dc.detach().clone(),
+             "grad_norm": out[1].clone(), "denom": out[2].clone(), "radii": out[3].clone()}
+    for v in views:
+        state[f"T{v.uid}"] = v.T.clone()
+        state[f"a{v.uid}"] = v.exposure_a.detach().clone()
+        state[f"tau{v.uid}"] = torch.cat([v.cam_trans_delta.detach(), v.cam_rot_delta.detach()])
+    return state
+
+
+def _mapping_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from monogs_amd.parallel import FlatGradBucket
+    gauss, views = _mapping_fixture()
+    local = [v for v in views if v.uid % world == rank]
+    bucket = FlatGradBucket([gauss._xyz, gauss._features_dc, gauss._opacity, gauss._scaling, gauss._rotation])
+    st = _run_mapping(gauss, local, [v.uid for v in local], bucket)
+    ret[rank] = {k: v.numpy() for k, v in st.items()}
+    dist.destroy_process_group()
+
+
+def test_sharded_mapping_step_matches_single_process_world2():
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    gauss, views = _mapping_fixture()
+    single = _run_mapping(gauss, views, None, None)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + ((os.getpid() + 137) % 500)
+    mp.spawn(_mapping_worker, args=(2, port, ret), nprocs=2, join=True)
+    for rank in (0, 1):
+        got = ret[rank]
+        for k in ("xyz", "scaling", "opacity", "rot", "fdc", "grad_norm", "denom", "radii"):
+            np.testing.assert_allclose(got[k], single[k].numpy(), rtol=2e-4, atol=2e-6, err_msg=f"rank {rank} {k}")
+        for uid in range(4):
+            if uid % 2 == rank:
+                for k in (f"T{uid}", f"a{uid}", f"tau{uid}"):
+                    np.testing.assert_allclose(got[k], single[k].numpy(), rtol=2e-4, atol=2e-6, err_msg=f"rank {rank} {k}")
+    # the pose gate uses the GLOBAL window position: view 3 (>= pose_window) keeps its deltas un-applied
+    assert np.abs(ret[1]["tau3"]).max() > 0 and np.abs(ret[1]["tau1"]).max() == 0

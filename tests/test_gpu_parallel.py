@@ -1,0 +1,113 @@
+"""2-rank rehearsal of the keyframe-parallel exchange on the GPU box.
+
+The box has ONE GPU, so both ranks share it and the collective runs over gloo with the flat
+buffer staged through the host (`FlatGradBucket._reduce`); the device-side work - rasteriser
+forward / backward per rank and the pack kernel - is the production path.  Checked: the reduced
+gradients and densification statistics equal the single-process sum over the same two views,
+and `bench.py --gpus 2` really starts two ranks and prints a 2-rank line with `exchange_ms`.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+N, W, H = 20000, 320, 240
+
+
+def _view_step(sc, params, rank_view, dev):
+    """forward + synthetic loss + backward of one view; returns (means2D grad, radii)."""
+    from monogs_amd import rasterizer as R, synthetic as S
+    from monogs_amd.parallel import view_pose
+    from monogs_amd.tracking_fused import l1_image_depth_loss
+    cam = S.make_camera(W, H, view_pose(rank_view))
+    st = R.GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, sc.bg.to(dev), 1.0,
+                                         cam.viewmatrix.to(dev), cam.projmatrix.to(dev),
+                                         cam.projmatrix_raw.to(dev), 0, cam.viewmatrix.to(dev), False, False)
+    m2d = torch.zeros(N, 3, device=dev, requires_grad=True)
+    img, radii, dep, opa, nt = R.GaussianRasterizer(st)(
+        means3D=params[0], means2D=m2d, shs=params[4], opacities=params[3], scales=params[1],
+        rotations=params[2])
+    l1_image_depth_loss(img, dep, sc.gt_image.to(dev), sc.gt_depth.to(dev), 0.05).backward()
+    return m2d.grad, radii
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from monogs_amd import synthetic as S
+    from monogs_amd.parallel import FlatGradBucket
+    sc = S.make_scene(N, W, H, seed=2)
+    params = [t.to(dev).requires_grad_() for t in S.activated(sc)]
+    g2d, radii = _view_step(sc, params, rank, dev)
+    bucket = FlatGradBucket(params)
+    stat, denom, max_radii = bucket.all_reduce(g2d, radii)
+    torch.cuda.synchronize()
+    if rank == 0:
+        reduced = [p.grad.clone() for p in params]
+        red_stat, red_den, red_rad = stat.clone(), denom.clone(), max_radii.clone()
+        # the same two views, one process: autograd accumulates the parameter gradients
+        for p in params:
+            p.grad = None
+        want_stat = torch.zeros(N, device=dev)
+        want_den = torch.zeros(N, device=dev)
+        want_rad = torch.zeros(N, dtype=torch.int32, device=dev)
+        for v in range(world):
+            g, r = _view_step(sc, params, v, dev)
+            vis = r > 0
+            want_stat += torch.where(vis, torch.linalg.norm(g[:, :2], dim=-1), torch.zeros_like(want_stat))
+            want_den += vis.float()
+            want_rad = torch.maximum(want_rad, r)
+        errs = [float((a - p.grad).abs().max() / (p.grad.abs().max() + 1e-30)) for a, p in zip(reduced, params)]
+        ret["grad_err"] = max(errs)
+        ret["grad_norms"] = [float(p.grad.norm()) for p in params]
+        ret["stat_err"] = float((red_stat - want_stat).abs().max() / (want_stat.abs().max() + 1e-30))
+        ret["den_ok"] = bool(torch.equal(red_den, want_den))
+        ret["rad_ok"] = bool(torch.equal(red_rad, want_rad))
+        ret["visible_both"] = int((want_den == 2).sum())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_exchange_equals_the_single_process_sum(built):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + ((os.getpid() + 251) % 500)
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret["visible_both"] > 1000          # the two views overlap: the sum is a real sum
+    assert all(n > 0 for n in ret["grad_norms"])
+    assert ret["grad_err"] < 1e-6, dict(ret)    # same kernels, fixed summation order: a + b exactly
+    assert ret["stat_err"] < 1e-6 and ret["den_ok"] and ret["rad_ok"], dict(ret)
+
+
+def test_bench_gpus_2_starts_two_ranks(built):
+    """`python bench.py --gpus 2` with no launcher around it (the form VERDICT r1 found dead)."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--gaussians", "20000", "--width", "320", "--height", "240", "--lean", "--profile-steps", "0"],
+                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["views_per_step"] == 2
+    mg = out["multi_gpu"]
+    assert len(mg["compute_ms_per_rank"]) == 2 and mg["exchange_ms"] > 0 and out["exchange_ms"] == mg["exchange_ms"]
+    assert mg["exchange_bytes"] == (20000 * (3 + 3 + 4 + 1 + 3) + 2 * 20000) * 4 + 20000 * 4
+    # a launcher whose world disagrees with --gpus is refused instead of silently running 1 rank
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--lean"], env=env2, cwd=ROOT,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r2.returncode != 0 and "WORLD_SIZE" in (r2.stderr + r2.stdout)
