@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MGS_ABI_VERSION 3
+#define MGS_ABI_VERSION 4
 
 typedef enum mgs_status {
   MGS_OK = 0,
@@ -99,7 +99,40 @@ typedef struct mgs_forward_args {
    * (device-accessible): the caller then learns D from an event recorded after stage 1
    * without a device-to-host copy in the stream. */
   int32_t* pair_count_out;
+  /* optional DEVICE counter: stage 1 does atomicMax(*pair_count_max, D).  Never reset by the
+   * library, so after any number of fixed-capacity forwards (mgs_tracking_iteration,
+   * mgs_mapping_view_iteration) *pair_count_max > pair_capacity says that at least one of them
+   * was rendered incompletely, whichever it was. */
+  int32_t* pair_count_max;
 } mgs_forward_args;
+
+/* Mapping mode of the backward (row a13, utils/slam_backend.py:171-332): instead of storing
+ * the gradients w.r.t. the ACTIVATED attributes of one view, the last kernel of the backward
+ * chains them through GaussianModel's activations (gaussian_model.py:54-62,77-102: exp, sigmoid,
+ * normalize, cat(features_dc, features_rest)) and accumulates them over the views of the window
+ * into the flat buffer the optimiser (and, keyframe-parallel, the all-reduce) consumes - what
+ * autograd's accumulation over the summed loss of slam_backend.py:183-247 does - together with
+ * the densification statistics of the view (gaussian_model.py:693-697, slam_backend.py:292-299).
+ * All pointers are device pointers into caller-owned buffers. */
+typedef struct mgs_map_accum_args {
+  int32_t scale_dims;           /* 3, or 1: isotropic model, _scaling is [N,1] (renderer broadcast :92-95) */
+  int32_t accumulate;           /* 0: overwrite (first view of an iteration), 1: add */
+  int32_t add_regulariser;      /* != 0: also add d/d_scaling of  weight * mean|s - mean_k(s)|
+                                   (slam_backend.py:244-246; once per iteration, every Gaussian) */
+  float regulariser_weight;     /* 10 in the reference */
+  const float* raw_rotations;   /* _rotation [N,4] before normalisation */
+  float* grad_xyz;              /* [N,3] */
+  float* grad_features_dc;      /* [N,1,3] */
+  float* grad_features_rest;    /* [N,K-1,3] or NULL when K == 1 */
+  float* grad_opacity;          /* [N]   w.r.t. the logit */
+  float* grad_scaling;          /* [N,scale_dims] w.r.t. the log scale */
+  float* grad_rotation;         /* [N,4] w.r.t. the raw quaternion */
+  float* gradnorm_inc;          /* [N] += ||dL/d ndc||  where radii > 0, or NULL */
+  float* denom_inc;             /* [N] += 1             where radii > 0, or NULL */
+  int32_t* radii_max;           /* [N] max over the views of radii, or NULL */
+  uint8_t* visibility;          /* [N] = n_touched > 0 of THIS view (occ-aware visibility,
+                                   slam_backend.py:251-255), or NULL */
+} mgs_map_accum_args;
 
 typedef struct mgs_backward_args {
   mgs_forward_args fwd;        /* same inputs / workspaces as the forward call */
@@ -130,6 +163,10 @@ typedef struct mgs_backward_args {
    * int per pixel suffices): [H,W] = stack * sketch_dim + bucket, or -1.  Used when
    * sketch_indices is NULL. */
   const int32_t* sketch_bucket_flat;
+  /* mapping mode (HOST pointer, or NULL): the seven per-Gaussian gradient pointers above must
+   * then be NULL, scales / rotations / opacities / shs of `fwd` must be the outputs of
+   * mgs_map_activate, and the gradients are chained and accumulated as described above. */
+  const mgs_map_accum_args* map_accum;
 } mgs_backward_args;
 
 int32_t mgs_abi_version(void);
@@ -137,7 +174,9 @@ int32_t mgs_abi_version(void);
  * 1 = mgs_workspace_sizes, 2 = mgs_forward_args, 3 = mgs_backward_args, 4 = mgs_pose_adam_args,
  * 5 = mgs_mapping_loss_args, 6 = mgs_lm_step_args, 7 = mgs_tracking_loss_args,
  * 8 = mgs_tracking_iter_args, 9 = mgs_sketch_residual_args, 10 = mgs_tracking_so_args,
- * 11 = mgs_adam_group, 12 = mgs_map_plan_args, 13 = mgs_gather_tensor, 14 = mgs_map_gather_args);
+ * 11 = mgs_adam_group, 12 = mgs_map_plan_args, 13 = mgs_gather_tensor, 14 = mgs_map_gather_args,
+ * 15 = mgs_map_accum_args, 16 = mgs_map_activate_args, 17 = mgs_mapping_view_args,
+ * 18 = mgs_map_finish_args, 19 = mgs_map_append_args);
  * -1 for an unknown index.  Lets a foreign-language binding verify its struct mirrors. */
 int32_t mgs_struct_size(int32_t which);
 const char* mgs_status_string(int32_t status);
@@ -199,6 +238,19 @@ typedef struct mgs_pose_adam_args {
   const float* projection;
   float* viewmatrix_out;
   float* projmatrix_out;
+  /* mgs_mapping_view_iteration extras (all 0 / NULL otherwise).  A NULL parameter pointer
+   * (cam_rot_delta, cam_trans_delta, exposure_a, exposure_b) skips that group even when its
+   * gradient is available.  no_pose_update != 0: step the deltas but leave T alone (the reference
+   * optimises the deltas of `frames_to_optimize` keyframes and applies update_pose to the first
+   * `pose_window` only, utils/slam_backend.py:452-474 vs :328-332).  loss_partials: [2,n] block sums of
+   * the mapping objective (colour, depth); loss = w_rgb * sum_c + w_depth * sum_d is stored to
+   * *loss_view and added to *loss_accum. */
+  int32_t no_pose_update;
+  const float* loss_partials;
+  int32_t num_loss_partials;
+  float loss_w_rgb, loss_w_depth;
+  float* loss_view;
+  float* loss_accum;
 } mgs_pose_adam_args;
 
 int32_t mgs_pose_adam_step(const mgs_pose_adam_args* args, void* stream);
@@ -497,6 +549,103 @@ typedef struct mgs_map_gather_args {
 } mgs_map_gather_args;
 
 int32_t mgs_map_gather(const mgs_map_gather_args* args, void* stream);
+
+/* ---- native mapping iteration (row a13: utils/slam_backend.py:171-332) -------------------- */
+
+/* GaussianModel's activations for one mapping iteration (gaussian_model.py:54-62,77-102), one
+ * launch: scales = exp(_scaling) (an isotropic [N,1] model is broadcast to 3 axes as the
+ * renderer does, gaussian_renderer/__init__.py:92-95), rotations = normalize(_rotation),
+ * opacities = sigmoid(_opacity), shs = cat(_features_dc, _features_rest).  `shs` may be NULL
+ * when K == 1: features_dc is then used in place. */
+typedef struct mgs_map_activate_args {
+  int32_t num_gaussians;
+  int32_t scale_dims;            /* 3 or 1 */
+  int32_t sh_coeffs;             /* K */
+  const float* log_scales;       /* [N,scale_dims] */
+  const float* raw_rotations;    /* [N,4] */
+  const float* opacity_logits;   /* [N] */
+  const float* features_dc;      /* [N,1,3] */
+  const float* features_rest;    /* [N,K-1,3] or NULL */
+  float* scales;                 /* out [N,3] */
+  float* rotations;              /* out [N,4] */
+  float* opacities;              /* out [N] */
+  float* shs;                    /* out [N,K,3] or NULL (K == 1) */
+} mgs_map_activate_args;
+
+int32_t mgs_map_activate(const mgs_map_activate_args* args, void* stream);
+
+/* One view of one mapping iteration as a fixed launch sequence with no host round trip
+ * (the body of the loops at utils/slam_backend.py:183-242 plus this view's share of :247-332):
+ *   camera matrices from T -> rasteriser forward at the caller's fixed pair capacity ->
+ *   mapping objective (utils/slam_utils.py:224-253) value + gradients in one pass ->
+ *   rasteriser backward in mapping mode (mgs_map_accum_args: gradients chained through the
+ *   activations and ACCUMULATED over the views, densification statistics, occ-aware visibility)
+ *   -> Adam on this view's (cam_rot_delta, cam_trans_delta, exposure_a, exposure_b) + update_pose
+ *   (mgs_pose_adam_args; the keyframe optimiser of :452-489 is per view, so its step commutes
+ *   with the other views).
+ * forward_only != 0 stops after the forward and only writes accum.visibility (the prune pass of
+ * :259-290 consumes nothing else).  loss.image / depth / grad_* / partial and adam.grad_* /
+ * *_partials are filled in by the call; loss.partial must hold
+ * mgs_mapping_loss_partial_count(HW) floats. */
+typedef struct mgs_mapping_view_args {
+  mgs_forward_args fwd;
+  void* bwd;                     /* bwd_bytes of backward scratch */
+  float* grad_image;             /* [3,H,W] scratch */
+  float* grad_depth;             /* [1,H,W] scratch, or NULL when loss.w_depth == 0 */
+  float* grad_tau;               /* [6] scratch */
+  mgs_mapping_loss_args loss;
+  mgs_pose_adam_args adam;
+  mgs_map_accum_args accum;
+  float* loss_view;              /* [1] out: this view's loss, or NULL */
+  float* loss_accum;             /* [1] += this view's loss, or NULL */
+  int32_t camera_matrices_valid;
+  int32_t forward_only;
+} mgs_mapping_view_args;
+
+int32_t mgs_mapping_loss_partial_count(int64_t num_pixels);
+/* Value and gradients of the mapping objective in one pass (upstream gradient 1 unless
+ * grad_out is given): grad_image / grad_depth are written, `partial` receives the block sums
+ * [4][*num_blocks_out] = colour residual, depth residual, d/da, d/db for a consumer that sums
+ * them (mgs_pose_adam_step: loss_partials / exposure_partials). */
+int32_t mgs_mapping_loss_fused(const mgs_mapping_loss_args* args, int32_t* num_blocks_out, void* stream);
+int32_t mgs_mapping_view_iteration(const mgs_mapping_view_args* args, void* stream);
+
+/* End of a mapping iteration (after the optional all-reduce of the flat buffer), one launch:
+ *   xyz_gradient_accum += gradnorm_inc, denom += denom_inc, max_radii2D = max(max_radii2D, radii_max)
+ * (slam_backend.py:292-299; max_radii2D is a float tensor in the reference), and optionally
+ * GaussianModel.reset_opacity / reset_opacity_nonvisible (gaussian_model.py:364-377 +
+ * replace_tensor_to_optimizer :470-483): opacity logit <- inverse_sigmoid(reset_value) for every
+ * Gaussian (reset_mode 1) or for those NOT visible in any view of this iteration, i.e.
+ * denom_inc == 0 (reset_mode 2), and the opacity group's Adam moments zeroed (all of them,
+ * as the reference does). */
+typedef struct mgs_map_finish_args {
+  int32_t num_gaussians;
+  const float* gradnorm_inc;     /* [N] or NULL (no statistics this iteration) */
+  const float* denom_inc;        /* [N] (also the visibility source of reset_mode 2) */
+  const int32_t* radii_max;      /* [N] */
+  float* xyz_gradient_accum;     /* [N] */
+  float* denom;                  /* [N] */
+  float* max_radii2D;            /* [N] */
+  int32_t reset_mode;            /* 0 none, 1 reset_opacity, 2 reset_opacity_nonvisible */
+  float reset_value;             /* 0.01 / 0.4 */
+  float* opacity_logits;         /* [N] (reset_mode != 0) */
+  float* opacity_exp_avg;        /* [N] or NULL */
+  float* opacity_exp_avg_sq;     /* [N] or NULL */
+} mgs_map_finish_args;
+
+int32_t mgs_map_finish_iteration(const mgs_map_finish_args* args, void* stream);
+
+/* GaussianModel.extend_from_pcd (gaussian_model.py:210-245 -> cat_tensors_to_optimizer :525-557,
+ * densification_postfix :559-593) in one launch: dst[t] = cat(old[t], new[t]) for up to
+ * MGS_GATHER_MAX_TENSORS row-major 32-bit tensors; new == NULL appends zeros (Adam moments). */
+typedef struct mgs_map_append_args {
+  mgs_gather_tensor tensors[MGS_GATHER_MAX_TENSORS];   /* src = old rows, dst = rebuilt rows, mode unused */
+  const void* new_rows[MGS_GATHER_MAX_TENSORS];        /* [rows_new, width] or NULL = zeros */
+  int32_t num_tensors;
+  int64_t rows_old, rows_new;
+} mgs_map_append_args;
+
+int32_t mgs_map_append(const mgs_map_append_args* args, void* stream);
 
 /* Per-kernel timing (diagnostics; used by bench.py for the roofline line).  While
  * enabled every kernel launch is bracketed by hipEvents on the launch stream.

@@ -10,9 +10,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmonogs_raster.so")
+# MGS_LIB_PATH: load another build of the SAME library (kernel experiments, the -DMGS_STAMP build)
+LIB_PATH = os.environ.get("MGS_LIB_PATH") or os.path.join(_HERE, "lib", "libmonogs_raster.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 EXPORTS = (
     "mgs_abi_version", "mgs_struct_size", "mgs_status_string", "mgs_raster_workspace_query",
@@ -23,7 +24,8 @@ EXPORTS = (
     "mgs_mapping_loss_backward", "mgs_camera_from_pose", "mgs_tracking_iteration",
     "mgs_adam_step_multi", "mgs_map_plan_blocks", "mgs_map_plan_count", "mgs_map_plan_emit",
     "mgs_map_gather", "mgs_pack_mapping_grads", "mgs_sketch_assign", "mgs_sketch_residual",
-    "mgs_tracking_iteration_second_order",
+    "mgs_tracking_iteration_second_order", "mgs_map_activate", "mgs_mapping_loss_partial_count",
+    "mgs_mapping_loss_fused", "mgs_mapping_view_iteration", "mgs_map_finish_iteration", "mgs_map_append",
 )
 
 _fp = C.c_void_p  # device pointers travel as plain addresses
@@ -47,7 +49,16 @@ class ForwardArgs(C.Structure):
     _fields_ = [("shape", RasterShape)] + [(n, _fp) for n in (
         "means3D", "scales", "rotations", "cov3D_precomp", "opacities", "shs", "colors_precomp",
         "viewmatrix", "projmatrix", "projmatrix_raw", "campos", "bg", "geom", "bins",
-        "out_color", "out_depth", "out_opacity", "radii", "n_touched", "pair_count_out")]
+        "out_color", "out_depth", "out_opacity", "radii", "n_touched", "pair_count_out",
+        "pair_count_max")]
+
+
+class MapAccumArgs(C.Structure):
+    _fields_ = ([("scale_dims", C.c_int32), ("accumulate", C.c_int32), ("add_regulariser", C.c_int32),
+                 ("regulariser_weight", C.c_float)]
+                + [(n, _fp) for n in ("raw_rotations", "grad_xyz", "grad_features_dc", "grad_features_rest",
+                                      "grad_opacity", "grad_scaling", "grad_rotation", "gradnorm_inc",
+                                      "denom_inc", "radii_max", "visibility")])
 
 
 class BackwardArgs(C.Structure):
@@ -56,7 +67,7 @@ class BackwardArgs(C.Structure):
         "grad_opacities", "grad_scales", "grad_rotations", "grad_cov3D", "grad_tau")]
         + [("sketch_mode", C.c_int32), ("sketch_dim", C.c_int32), ("stack_dim", C.c_int32),
            ("sketch_indices", _fp), ("grad_sketch_dtau", _fp), ("sketch_ws", _fp),
-           ("sketch_bucket_flat", _fp)])
+           ("sketch_bucket_flat", _fp), ("map_accum", C.POINTER(MapAccumArgs))])
 
 
 class PoseAdamArgs(C.Structure):
@@ -67,7 +78,9 @@ class PoseAdamArgs(C.Structure):
             "lr_rot", "lr_trans", "lr_a", "lr_b", "beta1", "beta2", "eps", "converged_threshold")]
         + [("tau_partials", _fp), ("num_tau_partials", C.c_int32), ("exposure_partials", _fp),
            ("num_exposure_partials", C.c_int32), ("projection", _fp), ("viewmatrix_out", _fp),
-           ("projmatrix_out", _fp)])
+           ("projmatrix_out", _fp), ("no_pose_update", C.c_int32), ("loss_partials", _fp),
+           ("num_loss_partials", C.c_int32), ("loss_w_rgb", C.c_float), ("loss_w_depth", C.c_float),
+           ("loss_view", _fp), ("loss_accum", _fp)])
 
 
 class MappingLossArgs(C.Structure):
@@ -136,6 +149,32 @@ class MapGatherArgs(C.Structure):
     _fields_ = [("tensors", GatherTensor * GATHER_MAX_TENSORS), ("num_tensors", C.c_int32),
                 ("rows", C.c_int64), ("num_children", C.c_int32), ("src_index", _fp),
                 ("rotations", _fp), ("log_scales", _fp), ("noise", _fp), ("noise_row", _fp)]
+
+
+class MapActivateArgs(C.Structure):
+    _fields_ = ([("num_gaussians", C.c_int32), ("scale_dims", C.c_int32), ("sh_coeffs", C.c_int32)]
+                + [(n, _fp) for n in ("log_scales", "raw_rotations", "opacity_logits", "features_dc",
+                                      "features_rest", "scales", "rotations", "opacities", "shs")])
+
+
+class MappingViewArgs(C.Structure):
+    _fields_ = [("fwd", ForwardArgs), ("bwd", _fp), ("grad_image", _fp), ("grad_depth", _fp), ("grad_tau", _fp),
+                ("loss", MappingLossArgs), ("adam", PoseAdamArgs), ("accum", MapAccumArgs),
+                ("loss_view", _fp), ("loss_accum", _fp), ("camera_matrices_valid", C.c_int32),
+                ("forward_only", C.c_int32)]
+
+
+class MapFinishArgs(C.Structure):
+    _fields_ = ([("num_gaussians", C.c_int32)]
+                + [(n, _fp) for n in ("gradnorm_inc", "denom_inc", "radii_max", "xyz_gradient_accum", "denom",
+                                      "max_radii2D")]
+                + [("reset_mode", C.c_int32), ("reset_value", C.c_float)]
+                + [(n, _fp) for n in ("opacity_logits", "opacity_exp_avg", "opacity_exp_avg_sq")])
+
+
+class MapAppendArgs(C.Structure):
+    _fields_ = [("tensors", GatherTensor * GATHER_MAX_TENSORS), ("new_rows", _fp * GATHER_MAX_TENSORS),
+                ("num_tensors", C.c_int32), ("rows_old", C.c_int64), ("rows_new", C.c_int64)]
 
 
 _lib = None
@@ -217,6 +256,18 @@ def lib():
         fn.argtypes = [C.POINTER(TrackingLossArgs), C.c_void_p]
     L.mgs_struct_size.restype = C.c_int32
     L.mgs_struct_size.argtypes = [C.c_int32]
+    L.mgs_map_activate.restype = C.c_int32
+    L.mgs_map_activate.argtypes = [C.POINTER(MapActivateArgs), C.c_void_p]
+    L.mgs_mapping_loss_partial_count.restype = C.c_int32
+    L.mgs_mapping_loss_partial_count.argtypes = [C.c_int64]
+    L.mgs_mapping_loss_fused.restype = C.c_int32
+    L.mgs_mapping_loss_fused.argtypes = [C.POINTER(MappingLossArgs), C.POINTER(C.c_int32), C.c_void_p]
+    L.mgs_mapping_view_iteration.restype = C.c_int32
+    L.mgs_mapping_view_iteration.argtypes = [C.POINTER(MappingViewArgs), C.c_void_p]
+    L.mgs_map_finish_iteration.restype = C.c_int32
+    L.mgs_map_finish_iteration.argtypes = [C.POINTER(MapFinishArgs), C.c_void_p]
+    L.mgs_map_append.restype = C.c_int32
+    L.mgs_map_append.argtypes = [C.POINTER(MapAppendArgs), C.c_void_p]
     if L.mgs_abi_version() != ABI_VERSION:
         raise NativeLibraryError(
             f"ABI mismatch: library {L.mgs_abi_version()} vs binding {ABI_VERSION}")
@@ -228,7 +279,8 @@ def struct_mirrors():
     """ctypes mirror of every argument struct, in mgs_struct_size() order."""
     return [RasterShape, WorkspaceSizes, ForwardArgs, BackwardArgs, PoseAdamArgs, MappingLossArgs,
             LMStepArgs, TrackingLossArgs, TrackingIterArgs, SketchResidualArgs, TrackingSOArgs,
-            AdamGroup, MapPlanArgs, GatherTensor, MapGatherArgs]
+            AdamGroup, MapPlanArgs, GatherTensor, MapGatherArgs, MapAccumArgs, MapActivateArgs,
+            MappingViewArgs, MapFinishArgs, MapAppendArgs]
 
 
 def check(status: int, what: str) -> None:

@@ -273,6 +273,65 @@ __global__ __launch_bounds__(256) void k_pack_grads(PackPack A) {
   }
 }
 
+// ---------------------------------------------------------------------------------
+// Native mapping iteration (row a13): the activations of GaussianModel for one iteration,
+// the end-of-iteration statistics fold / opacity reset, and keyframe insertion's row append.
+__global__ __launch_bounds__(256) void k_map_activate(mgs_map_activate_args A) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= A.num_gaussians) return;
+  if (A.scale_dims == 3) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) A.scales[3 * (size_t)i + k] = expf(A.log_scales[3 * (size_t)i + k]);
+  } else {
+    const float sc = expf(A.log_scales[i]);
+    A.scales[3 * (size_t)i] = sc; A.scales[3 * (size_t)i + 1] = sc; A.scales[3 * (size_t)i + 2] = sc;
+  }
+  const float4 q = reinterpret_cast<const float4*>(A.raw_rotations)[i];
+  // torch.nn.functional.normalize: q / max(|q|, 1e-12)
+  const float inv = 1.f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+  reinterpret_cast<float4*>(A.rotations)[i] = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+  A.opacities[i] = 1.f / (1.f + expf(-A.opacity_logits[i]));
+  if (A.shs) {
+    const int K = A.sh_coeffs;
+    float* dst = A.shs + (size_t)3 * K * i;
+#pragma unroll
+    for (int c = 0; c < 3; c++) dst[c] = A.features_dc[3 * (size_t)i + c];
+    for (int k = 3; k < 3 * K; k++) dst[k] = A.features_rest[(size_t)3 * (K - 1) * i + (k - 3)];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_map_finish(mgs_map_finish_args A, float reset_logit) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= A.num_gaussians) return;
+  if (A.gradnorm_inc) {
+    A.xyz_gradient_accum[i] += A.gradnorm_inc[i];
+    A.denom[i] += A.denom_inc[i];
+    A.max_radii2D[i] = fmaxf(A.max_radii2D[i], (float)A.radii_max[i]);
+  }
+  if (A.reset_mode != 0) {
+    if (A.reset_mode == 1 || !(A.denom_inc[i] > 0.f)) A.opacity_logits[i] = reset_logit;
+    if (A.opacity_exp_avg) A.opacity_exp_avg[i] = 0.f;
+    if (A.opacity_exp_avg_sq) A.opacity_exp_avg_sq[i] = 0.f;
+  }
+}
+
+struct AppendPack {
+  const unsigned int* old_rows[MGS_GATHER_MAX_TENSORS];
+  const unsigned int* new_rows[MGS_GATHER_MAX_TENSORS];
+  unsigned int* dst[MGS_GATHER_MAX_TENSORS];
+  int width[MGS_GATHER_MAX_TENSORS];
+  int n;
+  long long rows_old, rows_new;
+};
+
+__global__ __launch_bounds__(256) void k_map_append(AppendPack G) {
+  const int t = blockIdx.y;
+  if (t >= G.n) return;
+  const long long w = G.width[t], n_old = G.rows_old * w, total = (G.rows_old + G.rows_new) * w;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256)
+    G.dst[t][e] = e < n_old ? G.old_rows[t][e] : (G.new_rows[t] ? G.new_rows[t][e - n_old] : 0u);
+}
+
 }  // namespace mgs
 
 using namespace mgs;
@@ -374,6 +433,49 @@ int32_t mgs_map_gather(const mgs_map_gather_args* a, void* stream) {
   long long want = (a->rows * maxw + 255) / 256;
   if (want > 4096) want = 4096;
   launch("gather_rows", k_gather_rows, dim3((unsigned)want, (unsigned)a->num_tensors), dim3(256), (hipStream_t)stream, G);
+  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+}
+
+int32_t mgs_map_activate(const mgs_map_activate_args* a, void* stream) {
+  if (!a || a->num_gaussians < 1 || (a->scale_dims != 1 && a->scale_dims != 3) || a->sh_coeffs < 1 ||
+      !a->log_scales || !a->raw_rotations || !a->opacity_logits || !a->scales || !a->rotations || !a->opacities)
+    return MGS_ERR_BAD_ARGUMENT;
+  if (a->shs && (!a->features_dc || (a->sh_coeffs > 1 && !a->features_rest))) return MGS_ERR_BAD_ARGUMENT;
+  if (!a->shs && a->sh_coeffs != 1) return MGS_ERR_BAD_ARGUMENT;
+  launch("map_activate", k_map_activate, dim3((a->num_gaussians + 255) / 256), dim3(256), (hipStream_t)stream, *a);
+  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+}
+
+int32_t mgs_map_finish_iteration(const mgs_map_finish_args* a, void* stream) {
+  if (!a || a->num_gaussians < 1 || a->reset_mode < 0 || a->reset_mode > 2) return MGS_ERR_BAD_ARGUMENT;
+  if (a->gradnorm_inc && (!a->denom_inc || !a->radii_max || !a->xyz_gradient_accum || !a->denom || !a->max_radii2D))
+    return MGS_ERR_BAD_ARGUMENT;
+  if (a->reset_mode != 0 && (!a->opacity_logits || !(a->reset_value > 0.f) || !(a->reset_value < 1.f))) return MGS_ERR_BAD_ARGUMENT;
+  if (a->reset_mode == 2 && !a->denom_inc) return MGS_ERR_BAD_ARGUMENT;
+  if (!a->gradnorm_inc && a->reset_mode == 0) return MGS_OK;
+  // inverse_sigmoid(x) = log(x / (1 - x))   (gaussian_splatting/utils/general_utils.py)
+  const float logit = a->reset_mode ? (float)log((double)a->reset_value / (1.0 - (double)a->reset_value)) : 0.f;
+  launch("map_finish", k_map_finish, dim3((a->num_gaussians + 255) / 256), dim3(256), (hipStream_t)stream, *a, logit);
+  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+}
+
+int32_t mgs_map_append(const mgs_map_append_args* a, void* stream) {
+  if (!a || a->num_tensors < 1 || a->num_tensors > MGS_GATHER_MAX_TENSORS || a->rows_old < 0 || a->rows_new < 0)
+    return MGS_ERR_BAD_ARGUMENT;
+  if (a->rows_old + a->rows_new == 0) return MGS_OK;
+  AppendPack G;
+  long long maxw = 1;
+  for (int i = 0; i < a->num_tensors; i++) {
+    const mgs_gather_tensor& t = a->tensors[i];
+    if ((!t.src && a->rows_old > 0) || !t.dst || t.width < 1) return MGS_ERR_BAD_ARGUMENT;
+    G.old_rows[i] = (const unsigned int*)t.src; G.new_rows[i] = (const unsigned int*)a->new_rows[i];
+    G.dst[i] = (unsigned int*)t.dst; G.width[i] = t.width;
+    if (t.width > maxw) maxw = t.width;
+  }
+  G.n = a->num_tensors; G.rows_old = a->rows_old; G.rows_new = a->rows_new;
+  long long want = ((a->rows_old + a->rows_new) * maxw + 255) / 256;
+  if (want > 4096) want = 4096;
+  launch("map_append", k_map_append, dim3((unsigned)want, (unsigned)a->num_tensors), dim3(256), (hipStream_t)stream, G);
   return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
 }
 

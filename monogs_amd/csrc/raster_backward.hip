@@ -1,13 +1,14 @@
-// Backward pass of the rasteriser for gfx950 (CDNA4, wave64).  Atomic-free on the
-// gradient path:
-//   k_scan_*        exclusive scan of per-Gaussian pair counts -> pair_base (slot bases)
-//   k_blend_bwd     1 workgroup / tile: back-to-front replay; per splat the 10 screen-space
-//                   gradients are reduced over the tile's 256 pixels (DPP wave reduction +
-//                   LDS) and stored ONCE, with plain stores, at the pair's slot
+// Backward pass of the rasteriser for gfx950 (CDNA4, wave64).  Atomic-free on the gradient path:
+//   k_blend_bwd      1 wave / (tile, 64-splat segment), 4 pixels per lane (one per 8x8 quadrant):
+//                    front-to-back replay from the forward's per-segment checkpoint; per splat the
+//                    ten screen-space sums are reduced over the wave in registers (permlane swap +
+//                    DPP reduce-scatter) and stored ONCE, with plain stores, at the pair's slot
 //   k_preprocess_bwd 1 thread / Gaussian: streams its contiguous slots, chains to
-//                   means3D / scale / rot / SH / opacity / means2D and the per-Gaussian
-//                   pose gradient, block-reduced to one partial per workgroup
-//   k_tau_reduce    fixed-order sum of the partials -> grad_tau[6]
+//                    means3D / scale / rot / SH / opacity / means2D and the per-Gaussian pose
+//                    gradient, block-reduced to one partial per workgroup; in mapping mode it also
+//                    chains through the model's activations and accumulates over the views
+//   k_tau_reduce     fixed-order sum of the partials -> grad_tau[6]
+// (slot offsets come out of the forward's binning pass; no scan is launched here.)
 //
 // Replaces rasterize_gaussians_backward of the reference's CUDA extension (its
 // autograd.Function is invoked through gaussian_renderer/__init__.py:151-168; gradient
@@ -46,78 +47,6 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
   return v;
 }
 
-// Ten wave64 sums at once, written directly as v_add_f32_dpp (the compiler otherwise
-// SLP-packs the adds into v_pk_add_f32, which cannot carry a DPP modifier, and emits
-// v_mov_dpp + v_mov + v_pk_add: 150 instructions instead of 60).  Each DPP step runs over
-// the ten registers in turn, so a register is re-read nine instructions after it was
-// written (>= the 2 wait states a DPP read needs); the leading s_nop covers the first.
-// Totals land in lane 63.
-__device__ __forceinline__ void wave_sum10_to_lane63(float (&r)[10]) {
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %9, %9, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %6, %6, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %7, %7, %7 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %9, %9, %9 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %3, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %4, %4, %4 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %5, %5, %5 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %6, %6, %6 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %7, %7, %7 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %8, %8, %8 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %9, %9, %9 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %9, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "v_add_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "v_add_f32_dpp %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "v_add_f32_dpp %5, %5, %5 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "v_add_f32_dpp %6, %6, %6 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "v_add_f32_dpp %7, %7, %7 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "v_add_f32_dpp %8, %8, %8 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "v_add_f32_dpp %9, %9, %9 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-      "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-      "v_add_f32_dpp %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-      "v_add_f32_dpp %4, %4, %4 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-      "v_add_f32_dpp %5, %5, %5 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-      "v_add_f32_dpp %6, %6, %6 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-      "v_add_f32_dpp %7, %7, %7 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-      "v_add_f32_dpp %8, %8, %8 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-      "v_add_f32_dpp %9, %9, %9 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-      : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]));
-}
-
 // Slot of a Gaussian's first pair: pairs of one Gaussian are contiguous and Gaussians are
 // laid out in index order, so the gather pass streams.  The offsets come out of the forward
 // binning (block-local scan + scan of the block totals), no scan is launched here.
@@ -129,12 +58,12 @@ __device__ __forceinline__ int pair_slot_base(const KP& P, int idx) {
 // Blend backward, segment-parallel.  One wave per (tile, kSeg-splat segment) work item,
 // FOUR pixels per lane, one in each 8x8 quadrant of the tile.  The lane that stages a splat
 // also evaluates the culling bound on the four quadrant boxes; the wave then visits, per
-// splat, only the quadrants that can be reached (wave-uniform branches).  Packed fp32 is
-// deliberately not used: v_pk_fma_f32 occupies the SIMD for twice the cycles of
-// v_fma_f32, so it saves issue slots but no pipe time, whereas per-quadrant skipping
-// removes about half of the arithmetic for splats of a few pixels' extent.  The forward checkpointed the per-pixel blend state (T, prefix
-// colour F) in front of every segment, so items are independent: no serial chain over a
-// tile's whole list, ~D/kSeg equal-sized items instead of T ragged ones.
+// splat, only the quadrants that can be reached (wave-uniform scalar bit tests on ballot masks).
+// The quadrant body is written on float2 operands so that it maps onto v_pk_{add,mul,fma}_f32
+// (measured on gfx950: a packed FMA issues in about 1.25x the time of a scalar one).  The forward
+// checkpointed the per-pixel blend state (T, prefix colour F) in front of every segment, so items
+// are independent: no serial chain over a tile's whole list, ~D/kSeg equal-sized items instead of
+// T ragged ones.
 //
 // Front-to-back replay inside the segment.  With S = (C_final + T_final bg) - F_i (colour
 // still to come behind splat i, background included) the derivative of the pixel w.r.t. the
@@ -144,10 +73,11 @@ __device__ __forceinline__ int pair_slot_base(const KP& P, int idx) {
 // blend weight w = alpha T times a monomial of (dx, dy) / the pixel's upstream gradient:
 //   S1 = sum W, Sx = sum W dx, Sy = sum W dy, Sxx, Sxy, Syy      (mean2D, conic, opacity)
 //   Rr, Rg, Rb = sum w * dL/dC_ch,  Rd = sum w * dL/dD            (colour, depth)
-// The lane adds its four pixels, the 10 sums are reduced over the wave with DPP, lane 63
-// parks them in LDS, and after the loop each lane converts two splats' sums into the
-// 40-B pair record and stores it ONCE at the pair's slot (plain stores, no atomics,
-// fixed summation order => deterministic).
+// The lane adds its four pixels, the 10 sums are reduced over the wave in registers
+// (wave_reduce.h: the totals land in ten different lanes) and those lanes store their dword of
+// the pair's 40-B record at the pair's slot in ONE store instruction (plain stores, no atomics,
+// fixed summation order => deterministic).  The per-Gaussian conic / opacity map the raw sums to
+// screen-space gradients once, in k_preprocess_bwd.
 typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr float kLog2eB = 1.4426950408889634f;
 
@@ -163,8 +93,7 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
   static_assert(!(SKETCH && POSE), "POSE is a plain-mode variant");
   static_assert(kSeg == 64, "one staged record per lane");
   __shared__ float4 s_r0[kSeg], s_r1[kSeg];
-  __shared__ float2 s_r2[kSeg];
-  __shared__ unsigned char s_mask[kSeg];   // 4-bit quadrant reach masks (2624 B of LDS in all: 24 waves per CU)
+  __shared__ float2 s_r2[kSeg];             // 2560 B of LDS in all: 25 waves per CU
   __shared__ float4 s_coef[SKETCH ? kSeg : 1][9];   // per splat: 6 features x 6 tau components
   const int item = xcd_remap<kBwdChunk>(blockIdx.x), lane = threadIdx.x;
   if (item >= min(P.seg_offset[P.T], P.max_segs)) return;
@@ -235,6 +164,7 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
 
   // ---- stage the segment's records (one per lane): slot, raw conic, quadrant reach mask ---
   int slot = -1;
+  unsigned long long mq[4];
   {
     unsigned int mask4 = 0;
     if (lane < nb) {
@@ -268,7 +198,11 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
         }
       }
     }
-    s_mask[lane] = (unsigned char)mask4;
+    // quadrant reach masks of the whole segment as four wave-uniform 64-bit words (bit j = splat
+    // j reaches quadrant q): they live in SGPRs, so the walk below skips unreachable splats and
+    // quadrants with scalar bit tests - no LDS round trip in front of every splat
+#pragma unroll
+    for (int q = 0; q < 4; q++) mq[q] = __builtin_amdgcn_ballot_w64((mask4 >> q) & 1u);
   }
   if (dead) {
     if (!JONLY && slot >= 0) {
@@ -307,12 +241,8 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
   }
 
   unsigned long long written = 0ull;
-  for (int j = 0; j < nb; j++) {
-    // quadrants this splat can reach at all (exact bound, evaluated once by the staging lane)
-    const unsigned int m = __builtin_amdgcn_readfirstlane(s_mask[j]);
-    if (m == 0u) continue;
-    const float4 u = s_r0[j], v = s_r1[j];
-    const float2 bd2 = s_r2[j];
+  // one splat: (u, v, bd2) = its staged record, m = the quadrants it reaches
+  auto visit = [&](int j, const float4 u, const float4 v, const float2 bd2) {
     const v2f mu = {u.x, u.y}, RG = {v.z, v.w}, BD = {bd2.x, bd2.y};
     const int idx = base + j;
     const v2f* cf2 = reinterpret_cast<const v2f*>(&s_coef[SKETCH ? j : 0][0]);   // [feature][tau pair]
@@ -322,7 +252,10 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
     bool any = false;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      if (!(m & (1u << q))) continue;                 // wave-uniform
+      if (!((mq[q] >> j) & 1ull)) continue;          // wave-uniform (scalar bit test)
+#if defined(MGS_ABL) && (MGS_ABL == 2 || MGS_ABL == 3)
+      any = true; r0 += u.x; continue;
+#endif
       const v2f d = mu - Pq[q];
       const float pw = d.x * (u.z * d.x + u.w * d.y) + v.x * d.y * d.y;
       const float ar = v.y * __builtin_amdgcn_exp2f(pw);
@@ -369,6 +302,9 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
         }
       }
     }
+#if defined(MGS_ABL) && (MGS_ABL == 1 || MGS_ABL == 3)
+    if (any) { T[0] += r0 + R12.x + R34.x + r5 + R67.x + R89.x; any = false; }
+#endif
     if (!JONLY && any) {
       // the ten wave totals land in ten different lanes; each stores its own dword of the
       // pair's record (slot of splat j broadcast from lane j): one store instruction per splat
@@ -385,6 +321,33 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
       if (wofs >= 0 && sj >= 0) dst[wofs] = wextra ? eres : mres;
       written |= 1ull << j;
     }
+  };
+  // Walk over the splats that reach any quadrant (set bits of the union mask), two-way unrolled
+  // with the NEXT splat's record prefetched from LDS above the arithmetic of the current one, so
+  // that no LDS latency sits between two splats and no registers rotate.
+  unsigned long long todo = mq[0] | mq[1] | mq[2] | mq[3];
+#if defined(MGS_ABL) && MGS_ABL == 4
+  todo = 0ull;
+#endif
+  if (todo != 0ull) {
+    int j0 = __builtin_ctzll(todo);
+    float4 u0 = s_r0[j0], v0 = s_r1[j0];
+    float2 w0 = s_r2[j0];
+    while (true) {
+      todo &= todo - 1ull;
+      const int j1 = __builtin_ctzll(todo) & 63;       // todo == 0: harmless read of slot 63
+      const float4 u1 = s_r0[j1], v1 = s_r1[j1];
+      const float2 w1 = s_r2[j1];
+      __builtin_amdgcn_sched_barrier(0);               // keep the prefetch above the arithmetic
+      visit(j0, u0, v0, w0);
+      if (todo == 0ull) break;
+      todo &= todo - 1ull;
+      j0 = __builtin_ctzll(todo) & 63;
+      u0 = s_r0[j0]; v0 = s_r1[j0]; w0 = s_r2[j0];
+      __builtin_amdgcn_sched_barrier(0);
+      visit(j1, u1, v1, w1);
+      if (todo == 0ull) break;
+    }
   }
   if constexpr (SKETCH) {
     // pixel rows of different segments of a tile meet in pix_jac: float atomics, planar
@@ -399,6 +362,9 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
       }
     }
   }
+#if defined(MGS_ABL)
+  if (T[0] == 123.456f && slot >= 0) B.pair_grad[(size_t)slot * 3].x = T[0] + T[1] + T[2] + T[3] + gS[0] + gS[1] + gS[2] + gS[3];
+#endif
   // splats of the segment that no pixel reached: zero record
   if (!JONLY && slot >= 0 && !((written >> lane) & 1ull)) {
     float4* dst = B.pair_grad + (size_t)slot * 3;
@@ -499,6 +465,13 @@ __global__ __launch_bounds__(256) void k_sketch_bucket(KP P, KB B) {
 }
 
 // ---------------------------------------------------------------------------------
+// MAP (mapping mode, mgs_map_accum_args): instead of storing the gradients w.r.t. the activated
+// attributes of this view, chain them through GaussianModel's activations
+// (gaussian_model.py:54-62: scaling = exp, opacity = sigmoid, rotation = normalize) and
+// accumulate into the per-iteration gradient buffer of the raw parameters, add the isotropic
+// regulariser's gradient (slam_backend.py:244-246) and this view's densification statistics
+// (gaussian_model.py:693-697, slam_backend.py:292-299) and occ-aware visibility (:251-255).
+template <bool MAP>
 __global__ __launch_bounds__(kPreBlock) void k_preprocess_bwd(KP P, KB B) {
   __shared__ float s_tau[kPreBlock / 64][6];
   const int idx = blockIdx.x * kPreBlock + threadIdx.x;
@@ -525,7 +498,7 @@ __global__ __launch_bounds__(kPreBlock) void k_preprocess_bwd(KP P, KB B) {
         a[4] += y.x; a[5] += y.y; a[6] += y.z; a[7] += y.w;
         a[8] += z.x; a[9] += z.y;
       }
-      if (!B.g_means3D) { a[0] = 0.f; a[6] = 0.f; a[7] = 0.f; a[8] = 0.f; }   // pose-only: not produced
+      if (!MAP && !B.g_means3D) { a[0] = 0.f; a[6] = 0.f; a[7] = 0.f; a[8] = 0.f; }   // pose-only: not produced
       // a[] = raw pixel sums (S1, Sx, Sy, Sxx, Sxy, Syy, Rr, Rg, Rb, Rd) over all tiles of
       // the Gaussian; the conic / opacity are per-Gaussian, so the linear map to screen-space
       // gradients is applied once here instead of once per pair
@@ -557,7 +530,75 @@ __global__ __launch_bounds__(kPreBlock) void k_preprocess_bwd(KP P, KB B) {
       dndc[0] = gg.dndc[0]; dndc[1] = gg.dndc[1];
       dop = gg.dop;
     }
-    if (B.g_means3D) {   // NULL: pose-only backward (tracking), nothing per Gaussian is stored
+    if constexpr (MAP) {
+      const KM& M = B.map;
+      const bool add = M.accumulate != 0;
+      auto put = [&](float* dst, float v) { *dst = add ? *dst + v : v; };
+      // colour coefficients first: for degree > 0 sh_backward adds the view-direction term to dmean
+      {
+        float dsh[48];
+        if (radius > 0 && P.shs) {
+          if (P.deg == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) dsh[c] = (flags & (1u << c)) ? 0.f : SH_C0 * grgb[c];
+            for (int k = 3; k < 3 * P.K; k++) dsh[k] = 0.f;
+          } else {
+            sh_backward(P.deg, P.K, P.shs + (size_t)3 * P.K * idx, p, P.campos, flags, grgb, dsh, dmean);
+          }
+        } else {
+          for (int k = 0; k < 3 * P.K; k++) dsh[k] = 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) put(&M.g_fdc[3 * (size_t)idx + c], dsh[c]);
+        if (M.g_frest)
+          for (int k = 3; k < 3 * P.K; k++) put(&M.g_frest[(size_t)3 * (P.K - 1) * idx + (k - 3)], dsh[k]);
+      }
+#pragma unroll
+      for (int i = 0; i < 3; i++) put(&M.g_xyz[3 * (size_t)idx + i], dmean[i]);
+      // opacity = sigmoid(logit)
+      const float o = P.opac[idx];
+      put(&M.g_opacity[idx], dop * o * (1.f - o));
+      // scaling = exp(log scale) (+ regulariser: weight * mean_{N x 3} |s_k - mean_k s|)
+      {
+        const float s0 = P.scales[3 * idx], s1 = P.scales[3 * idx + 1], s2 = P.scales[3 * idx + 2];
+        float g0 = dscale[0] * s0, g1 = dscale[1] * s1, g2 = dscale[2] * s2;
+        if (M.scale_dims == 3) {
+          if (M.add_reg) {
+            const float mean = (s0 + s1 + s2) * (1.f / 3.f);
+            auto sg = [](float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); };
+            const float e0 = sg(s0 - mean), e1 = sg(s1 - mean), e2 = sg(s2 - mean);
+            const float em = (e0 + e1 + e2) * (1.f / 3.f);
+            g0 += M.reg_scale * (e0 - em) * s0;
+            g1 += M.reg_scale * (e1 - em) * s1;
+            g2 += M.reg_scale * (e2 - em) * s2;
+          }
+          put(&M.g_scaling[3 * (size_t)idx], g0);
+          put(&M.g_scaling[3 * (size_t)idx + 1], g1);
+          put(&M.g_scaling[3 * (size_t)idx + 2], g2);
+        } else {   // isotropic [N,1] broadcast: the three axes share one parameter (regulariser = 0)
+          put(&M.g_scaling[idx], g0 + g1 + g2);
+        }
+      }
+      // rotation = q / |q|:  dL/dq = (g - qn (qn . g)) / |q|
+      {
+        const float4 qr = reinterpret_cast<const float4*>(M.raw_rot)[idx];
+        const float n2 = qr.x * qr.x + qr.y * qr.y + qr.z * qr.z + qr.w * qr.w;
+        const float inv = 1.f / fmaxf(sqrtf(n2), 1e-12f);
+        const float qn[4] = {qr.x * inv, qr.y * inv, qr.z * inv, qr.w * inv};
+        const float dot = qn[0] * drot[0] + qn[1] * drot[1] + qn[2] * drot[2] + qn[3] * drot[3];
+        float4* dst = reinterpret_cast<float4*>(M.g_rotation) + idx;
+        float4 gq = make_float4((drot[0] - qn[0] * dot) * inv, (drot[1] - qn[1] * dot) * inv,
+                                (drot[2] - qn[2] * dot) * inv, (drot[3] - qn[3] * dot) * inv);
+        if (add) { const float4 old = *dst; gq.x += old.x; gq.y += old.y; gq.z += old.z; gq.w += old.w; }
+        *dst = gq;
+      }
+      // statistics of this view
+      const bool vis = radius > 0;
+      if (M.gradnorm_inc) put(&M.gradnorm_inc[idx], vis ? sqrtf(dndc[0] * dndc[0] + dndc[1] * dndc[1]) : 0.f);
+      if (M.denom_inc) put(&M.denom_inc[idx], vis ? 1.f : 0.f);
+      if (M.radii_max) M.radii_max[idx] = add ? max(M.radii_max[idx], radius) : radius;
+      if (M.visibility) M.visibility[idx] = P.n_touched[idx] > 0 ? 1 : 0;
+    } else if (B.g_means3D) {   // NULL: pose-only backward (tracking), nothing per Gaussian is stored
     // colours
     if (P.shs) {
       float* dsh = B.g_colors + (size_t)3 * P.K * idx;
@@ -601,6 +642,12 @@ __global__ __launch_bounds__(kPreBlock) void k_preprocess_bwd(KP P, KB B) {
   }
 }
 
+// occ-aware visibility of a forward-only (prune) pass: slam_backend.py:251-255
+__global__ void k_visibility_only(const int* n_touched, unsigned char* vis, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) vis[i] = n_touched[i] > 0 ? 1 : 0;
+}
+
 // Fixed-order sum of the block partials -> grad_tau[6].  (Folding this into k_preprocess_bwd
 // with a last-workgroup ticket was measured slower: the hand-off makes every workgroup drain
 // its 20 MB of gradient stores before it may retire.)
@@ -611,6 +658,11 @@ __global__ __launch_bounds__(384) void k_tau_reduce(KB B, int nblk) {
   for (int i = lane; i < nblk; i += 64) s += B.tau_partial[i * 6 + comp];
   s = wave_sum_to_lane63(s);
   if (lane == 63) B.g_tau[comp] = s;
+}
+
+int launch_visibility(const int* n_touched, unsigned char* vis, int n, hipStream_t st) {
+  launch("visibility", k_visibility_only, dim3((n + 255) / 256), dim3(256), st, n_touched, vis, n);
+  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
 // ---------------------------------------------------------------------------------
@@ -630,13 +682,14 @@ int launch_backward(const KP& P, const KB& B, hipStream_t st, bool skip_tau_redu
     launch_smem("sketch_bucket", k_sketch_bucket, dim3(kBucketBlocks), dim3(256), nacc * sizeof(float), st, P, B);
     if (B.sketch_only) return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
   } else {
-    if (B.g_means3D)
+    if (B.g_means3D || B.map.on)
       launch("blend_bwd", k_blend_bwd<false>, dim3(grid_pad(P.max_segs, kBwdChunk)), dim3(64), st, P, B);
     else   // pose-only (tracking)
       launch("blend_bwd", k_blend_bwd<false, false, true>, dim3(grid_pad(P.max_segs, kBwdChunk)), dim3(64), st, P, B);
   }
   const int npre = (P.N + kPreBlock - 1) / kPreBlock;
-  launch("preprocess_bwd", k_preprocess_bwd, dim3(npre), dim3(kPreBlock), st, P, B);
+  if (B.map.on) launch("preprocess_bwd_map", k_preprocess_bwd<true>, dim3(npre), dim3(kPreBlock), st, P, B);
+  else launch("preprocess_bwd", k_preprocess_bwd<false>, dim3(npre), dim3(kPreBlock), st, P, B);
   if (!skip_tau_reduce) launch("tau_reduce", k_tau_reduce, dim3(1), dim3(384), st, B, npre);
   return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
 }

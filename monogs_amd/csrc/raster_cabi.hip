@@ -26,6 +26,7 @@ int launch_forward_project(const KP& P, hipStream_t st);
 int launch_forward_blend(const KP& P, hipStream_t st);
 int launch_backward(const KP& P, const KB& B, hipStream_t st, bool skip_tau_reduce);
 int launch_knn(const float* pts, int n, float* out, void* scratch, hipStream_t st);
+int launch_visibility(const int* n_touched, unsigned char* vis, int n, hipStream_t st);
 uint64_t knn_scratch_bytes(int n);
 }  // namespace mgs
 
@@ -87,7 +88,7 @@ int fill_kp(const mgs_forward_args& a, bool need_bins, bool need_outputs, KP& P)
   P.ckpt = b ? (float*)(b + L.ckpt) : nullptr;
   P.max_segs = (int)L.max_segs;
   P.out_color = a.out_color; P.out_depth = a.out_depth; P.out_opacity = a.out_opacity;
-  P.radii = a.radii; P.n_touched = a.n_touched; P.d_out = a.pair_count_out;
+  P.radii = a.radii; P.n_touched = a.n_touched; P.d_out = a.pair_count_out; P.d_max = a.pair_count_max;
   return MGS_OK;
 }
 
@@ -114,6 +115,11 @@ int32_t mgs_struct_size(int32_t which) {
     case 12: return (int32_t)sizeof(mgs_map_plan_args);
     case 13: return (int32_t)sizeof(mgs_gather_tensor);
     case 14: return (int32_t)sizeof(mgs_map_gather_args);
+    case 15: return (int32_t)sizeof(mgs_map_accum_args);
+    case 16: return (int32_t)sizeof(mgs_map_activate_args);
+    case 17: return (int32_t)sizeof(mgs_mapping_view_args);
+    case 18: return (int32_t)sizeof(mgs_map_finish_args);
+    case 19: return (int32_t)sizeof(mgs_map_append_args);
     default: return -1;
   }
 }
@@ -165,12 +171,21 @@ static int32_t raster_backward_impl(const mgs_backward_args* args, void* stream,
   const int rc = fill_kp(args->fwd, true, false, P);
   if (rc != MGS_OK) return rc;
   if (!args->grad_color || !args->bwd || !args->grad_tau) return MGS_ERR_BAD_ARGUMENT;
-  {   // per-Gaussian gradients: all of the mandatory four, or none at all (pose-only)
+  {   // per-Gaussian gradients: all of the mandatory four, or none at all (pose-only / mapping mode)
     const int have = (args->grad_means3D != nullptr) + (args->grad_means2D != nullptr) +
                      (args->grad_colors != nullptr) + (args->grad_opacities != nullptr);
     if (have != 0 && have != 4) return MGS_ERR_BAD_ARGUMENT;
     if (have == 0 && (args->grad_scales || args->grad_rotations || args->grad_cov3D))
       return MGS_ERR_BAD_ARGUMENT;
+    if (args->map_accum) {
+      const mgs_map_accum_args& m = *args->map_accum;
+      if (have != 0 || args->sketch_mode != 0 || !args->fwd.scales || !args->fwd.rotations || !args->fwd.shs ||
+          args->fwd.cov3D_precomp || args->fwd.colors_precomp || (m.scale_dims != 1 && m.scale_dims != 3) ||
+          !m.raw_rotations || !m.grad_xyz || !m.grad_features_dc || !m.grad_opacity || !m.grad_scaling ||
+          !m.grad_rotation || (args->fwd.shape.sh_coeffs > 1 && !m.grad_features_rest) ||
+          ((m.gradnorm_inc != nullptr) != (m.denom_inc != nullptr)) || (m.visibility && !args->fwd.n_touched))
+        return MGS_ERR_BAD_ARGUMENT;
+    }
   }
   if (args->sketch_mode != 0 &&
       ((!args->sketch_indices && !args->sketch_bucket_flat) || !args->grad_sketch_dtau || !args->sketch_ws ||
@@ -193,6 +208,19 @@ static int32_t raster_backward_impl(const mgs_backward_args* args, void* stream,
   char* sw = (char*)args->sketch_ws;
   B.pix_jac = sw ? (float*)(sw + L.pix_jac) : nullptr;
   B.splat_jac = sw ? (float*)(sw + L.splat_jac) : nullptr;
+  memset(&B.map, 0, sizeof(B.map));
+  if (args->map_accum) {
+    const mgs_map_accum_args& m = *args->map_accum;
+    KM& M = B.map;
+    M.on = 1; M.scale_dims = m.scale_dims; M.accumulate = m.accumulate; M.add_reg = m.add_regulariser;
+    M.reg_scale = m.regulariser_weight / (3.0f * (float)P.N);
+    M.raw_rot = m.raw_rotations;
+    M.g_xyz = m.grad_xyz; M.g_fdc = m.grad_features_dc; M.g_frest = m.grad_features_rest;
+    M.g_opacity = m.grad_opacity; M.g_scaling = m.grad_scaling; M.g_rotation = m.grad_rotation;
+    M.gradnorm_inc = m.gradnorm_inc; M.denom_inc = m.denom_inc; M.radii_max = m.radii_max;
+    M.visibility = m.visibility;
+    P.n_touched = args->fwd.n_touched;
+  }
   if (tau_partials) *tau_partials = B.tau_partial;
   if (num_partials) *num_partials = (P.N + kPreBlock - 1) / kPreBlock;
   return launch_backward(P, B, (hipStream_t)stream, skip_tau_reduce);
@@ -237,6 +265,61 @@ int32_t mgs_tracking_iteration(const mgs_tracking_iter_args* args, void* stream)
   A.grad_trans = nullptr; A.grad_rot = nullptr; A.grad_a = nullptr; A.grad_b = nullptr;
   A.tau_partials = tau_partials; A.num_tau_partials = npre;
   A.exposure_partials = L.partial + nblk; A.num_exposure_partials = nblk;
+  A.projection = args->fwd.projmatrix_raw;
+  A.viewmatrix_out = const_cast<float*>(args->fwd.viewmatrix);
+  A.projmatrix_out = const_cast<float*>(args->fwd.projmatrix);
+  return mgs_pose_adam_step(&A, stream);
+}
+
+int32_t mgs_mapping_view_iteration(const mgs_mapping_view_args* args, void* stream) {
+  if (!args || !args->adam.T || !args->fwd.viewmatrix || !args->fwd.projmatrix || args->fwd.shape.pair_capacity < 1)
+    return MGS_ERR_BAD_ARGUMENT;
+  if (!args->forward_only && (!args->bwd || !args->grad_image || !args->grad_tau || !args->loss.partial || !args->loss.gt))
+    return MGS_ERR_BAD_ARGUMENT;
+  int32_t rc = MGS_OK;
+  if (!args->camera_matrices_valid) {
+    rc = mgs_camera_from_pose(args->adam.T, args->fwd.projmatrix_raw, const_cast<float*>(args->fwd.viewmatrix),
+                              const_cast<float*>(args->fwd.projmatrix), stream);
+    if (rc != MGS_OK) return rc;
+  }
+  if ((rc = mgs_raster_forward_project(&args->fwd, stream)) != MGS_OK) return rc;
+  if ((rc = mgs_raster_forward_blend(&args->fwd, stream)) != MGS_OK) return rc;
+  if (args->forward_only) {
+    if (args->accum.visibility) {
+      return launch_visibility((const int*)args->fwd.n_touched, args->accum.visibility,
+                               args->fwd.shape.num_gaussians, (hipStream_t)stream);
+    }
+    return MGS_OK;
+  }
+  // objective: value + gradients in one pass; the block sums are consumed by the Adam kernel
+  mgs_mapping_loss_args L = args->loss;
+  L.image = args->fwd.out_color; L.depth = args->fwd.out_depth;
+  L.grad_image = args->grad_image; L.grad_depth = L.w_depth != 0.f ? args->grad_depth : nullptr;
+  L.grad_out = nullptr;
+  int32_t nblk = 0;
+  if ((rc = mgs_mapping_loss_fused(&L, &nblk, stream)) != MGS_OK) return rc;
+  // full backward in mapping mode
+  mgs_backward_args B;
+  memset(&B, 0, sizeof(B));
+  B.fwd = args->fwd;
+  B.grad_color = args->grad_image;
+  B.grad_depth = L.grad_depth;
+  B.bwd = args->bwd;
+  B.grad_tau = args->grad_tau;
+  B.map_accum = &args->accum;
+  const float* tau_partials = nullptr;
+  int32_t npre = 0;
+  if ((rc = raster_backward_impl(&B, stream, true, &tau_partials, &npre)) != MGS_OK) return rc;
+  // this view's pose / exposure optimiser step (+ update_pose), loss value
+  mgs_pose_adam_args A = args->adam;
+  A.grad_trans = nullptr; A.grad_rot = nullptr; A.grad_a = nullptr; A.grad_b = nullptr;
+  A.tau_partials = tau_partials; A.num_tau_partials = npre;
+  A.exposure_partials = L.apply_exposure ? L.partial + 2 * nblk : nullptr; A.num_exposure_partials = nblk;
+  if (!L.apply_exposure) { A.exposure_a = nullptr; A.exposure_b = nullptr; }
+  A.loss_partials = L.partial; A.num_loss_partials = nblk;
+  const float hw = (float)L.num_pixels;
+  A.loss_w_rgb = L.w_rgb / (3.f * hw); A.loss_w_depth = L.w_depth / hw;
+  A.loss_view = args->loss_view; A.loss_accum = args->loss_accum;
   A.projection = args->fwd.projmatrix_raw;
   A.viewmatrix_out = const_cast<float*>(args->fwd.viewmatrix);
   A.projmatrix_out = const_cast<float*>(args->fwd.projmatrix);

@@ -1,12 +1,18 @@
 // Forward pass of the rasteriser for gfx950 (CDNA4, wave64).
 //
 // Pipeline (one launch each, all on the caller's stream, no host sync):
-//   k_preprocess   1 thread / Gaussian : projection + EWA -> 48-B SplatRec      (HBM bound)
-//   k_bin<count>   1 thread / Gaussian : exact tile culling, per-tile counts    (HBM + int atomics)
-//   k_tile_scan    1 workgroup         : exclusive scan of T tile counts -> D
-//   k_bin<emit>    1 thread / Gaussian : (depth|id, j) pairs into per-tile segments
-//   k_tile_sort    1 workgroup / tile  : LDS bitonic sort of the tile's segment by (depth,id)
-//   k_blend_fwd    1 workgroup / tile  : LDS-staged front-to-back alpha blend
+//   k_preprocess     1 thread / Gaussian : projection + EWA -> 48-B SplatRec          (HBM bound)
+//   k_bin_lds<count> 1024-thread workgroup per contiguous chunk of Gaussians: exact tile culling,
+//                    per-chunk tile histogram in LDS (no global atomics), per-Gaussian slot offsets
+//   k_bin_colsum     column prefix of the chunk histograms -> per-chunk bases and tile totals; the
+//                    workgroup that finishes last also scans the tile totals (-> tile_offset, D)
+//   k_bin_lds<emit>  same walk: (depth | id | pair index) keys into the tiles' ranges
+//   k_tile_sort      1 workgroup / tile  : LDS bitonic sort of the tile's range by (depth, id);
+//                    two size classes (<= 1024, <= 4096 keys), larger tiles sort in place in HBM
+//   k_blend_fwd      1 wave / 8x8 quadrant (its own 64-thread workgroup): front-to-back blend over
+//                    the tile's sorted list, 64 splats staged in LDS at a time, per-pixel state
+//                    checkpointed every 64 splats for the segment-parallel backward
+// (k_bin / k_scan_* / k_tile_scan: fallback for images with more tiles than fit an LDS table.)
 //
 // Replaces rasterize_gaussians (forward) of the reference's CUDA extension, called at
 // /root/reference gaussian_splatting/gaussian_renderer/__init__.py:151-168.
@@ -344,6 +350,7 @@ __device__ __forceinline__ void tile_scan_body(const KP& P, int nbin, int* s_sum
     P.counters[0] = s_sum[1023];
     P.counters[1] = s_seg[1023];
     if (P.d_out) __hip_atomic_store(P.d_out, s_sum[1023], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (P.d_max) atomicMax(P.d_max, s_sum[1023]);
   }
 }
 
@@ -703,6 +710,9 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
       auto walk = [&](auto touch_tag) {
         constexpr bool kTouch = decltype(touch_tag)::value;
         auto visit = [&](int j, const float4 u, const float4 v, const float2 bd) {
+#if defined(MGS_ABL) && MGS_ABL == 5
+          T -= 1e-9f * u.x; return;
+#endif
           const float dx = u.x - fpx, dy = u.y - fpy;
           const float pw = dx * (u.z * dx + u.w * dy) + v.x * dy * dy;
           const float araw = v.y * __builtin_amdgcn_exp2f(pw);

@@ -42,6 +42,17 @@ struct KP {
   float *out_color, *out_depth, *out_opacity;
   int *radii, *n_touched;
   int* d_out;              // optional extra destination of D (may be pinned host memory)
+  int* d_max;              // optional sticky high-water mark of D (atomicMax)
+};
+
+struct KM {   // mapping mode of the preprocess backward (mgs_map_accum_args)
+  int on, scale_dims, accumulate, add_reg;
+  float reg_scale;          // weight / (3 N)
+  const float* raw_rot;
+  float *g_xyz, *g_fdc, *g_frest, *g_opacity, *g_scaling, *g_rotation;
+  float *gradnorm_inc, *denom_inc;
+  int* radii_max;
+  unsigned char* visibility;
 };
 
 struct KB {   // backward extras
@@ -56,6 +67,7 @@ struct KB {   // backward extras
   float* g_sketch;
   float* pix_jac;          // W*H x 6 per-pixel pose-Jacobian rows (sketch mode)
   float* splat_jac;        // N x 36 per-splat d(xy,conic,depth)/dtau (sketch mode)
+  KM map;
 };
 
 // XCD-aware work-item order (cdna_hip_programming.md T1): workgroups are dealt round-robin

@@ -58,8 +58,22 @@ __global__ __launch_bounds__(512) void k_pose_adam_update(mgs_pose_adam_args A) 
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     if (lane == 0) s_g[6 + c] = v;
   }
+  __shared__ float s_loss[2];
+  if (A.loss_partials && wave >= 6) {      // mapping objective: colour / depth block sums
+    const int c = wave - 6;
+    float v = 0.f;
+#pragma unroll 8
+    for (int i = lane; i < A.num_loss_partials; i += 64) v += A.loss_partials[c * A.num_loss_partials + i];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if (lane == 0) s_loss[c] = v;
+  }
   __syncthreads();
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (A.loss_partials) {
+    const float l = A.loss_w_rgb * s_loss[0] + A.loss_w_depth * s_loss[1];
+    if (A.loss_view) A.loss_view[0] = l;
+    if (A.loss_accum) A.loss_accum[0] += l;
+  }
   float* P[4] = {A.cam_rot_delta, A.cam_trans_delta, A.exposure_a, A.exposure_b};
   const float* G[4] = {A.tau_partials ? &s_g[0] : A.grad_rot, A.tau_partials ? &s_g[3] : A.grad_trans,
                        A.exposure_partials ? (A.exposure_a ? &s_g[6] : nullptr) : A.grad_a,
@@ -71,7 +85,7 @@ __global__ __launch_bounds__(512) void k_pose_adam_update(mgs_pose_adam_args A) 
   int off = 0;
   for (int g = 0; g < 4; g++) {
     for (int i = 0; i < len[g]; i++, off++) {
-      if (!G[g]) continue;
+      if (!G[g] || !P[g]) continue;
       const float gr = G[g][i];
       const float m = A.beta1 * A.exp_avg[off] + (1.f - A.beta1) * gr;
       const float v = A.beta2 * A.exp_avg_sq[off] + (1.f - A.beta2) * gr * gr;
@@ -81,8 +95,9 @@ __global__ __launch_bounds__(512) void k_pose_adam_update(mgs_pose_adam_args A) 
     }
   }
   if (A.T) {
-    const float th[3] = {A.cam_rot_delta[0], A.cam_rot_delta[1], A.cam_rot_delta[2]};
-    const float rho[3] = {A.cam_trans_delta[0], A.cam_trans_delta[1], A.cam_trans_delta[2]};
+    const bool move = !A.no_pose_update && A.cam_rot_delta && A.cam_trans_delta;
+    const float th[3] = {move ? A.cam_rot_delta[0] : 0.f, move ? A.cam_rot_delta[1] : 0.f, move ? A.cam_rot_delta[2] : 0.f};
+    const float rho[3] = {move ? A.cam_trans_delta[0] : 0.f, move ? A.cam_trans_delta[1] : 0.f, move ? A.cam_trans_delta[2] : 0.f};
     float R[9], V[9];
     so3_exp_V(th, R, V);
     float t[3];
@@ -92,11 +107,11 @@ __global__ __launch_bounds__(512) void k_pose_adam_update(mgs_pose_adam_args A) 
       for (int j = 0; j < 4; j++)
         Tn[4 * i + j] = R[3 * i] * A.T[j] + R[3 * i + 1] * A.T[4 + j] + R[3 * i + 2] * A.T[8 + j] +
                         (j == 3 ? t[i] : 0.f) * A.T[15];
-    for (int i = 0; i < 12; i++) A.T[i] = Tn[i];
+    if (move) for (int i = 0; i < 12; i++) A.T[i] = Tn[i];
     const float n2 = th[0] * th[0] + th[1] * th[1] + th[2] * th[2] + rho[0] * rho[0] + rho[1] * rho[1] +
                      rho[2] * rho[2];
     if (A.converged) *A.converged = n2 < A.converged_threshold * A.converged_threshold ? 1 : 0;
-    for (int i = 0; i < 3; i++) { A.cam_rot_delta[i] = 0.f; A.cam_trans_delta[i] = 0.f; }
+    if (move) for (int i = 0; i < 3; i++) { A.cam_rot_delta[i] = 0.f; A.cam_trans_delta[i] = 0.f; }
     if (A.viewmatrix_out && A.projmatrix_out && A.projection) {   // matrices of the updated pose
       for (int i = 0; i < 4; i++)
         for (int j = 0; j < 4; j++) {
@@ -422,6 +437,56 @@ __global__ __launch_bounds__(kLossBlock) void k_map_loss_bwd_finish(mgs_mapping_
   }
 }
 
+// Value AND gradients of the mapping objective in ONE pass (mgs_mapping_view_iteration): the L1
+// gradient does not depend on the loss value, so nothing has to wait for a reduction.  Block
+// partials [4][n]: sum |colour residual|, sum |depth residual|, d/da, d/db; their consumer
+// (k_pose_adam_update) sums them in a fixed order.  The upstream gradient is 1 unless
+// A.grad_out is given.
+__global__ __launch_bounds__(kLossBlock) void k_map_loss_fused(mgs_mapping_loss_args A) {
+  __shared__ float s_red[kLossBlock / 64];
+  const float a = A.apply_exposure ? A.exposure_a[0] : 1.f;
+  const float gain = A.apply_exposure ? fabsf(a) + A.exposure_eps : 1.f;
+  const float bias = A.apply_exposure ? A.exposure_b[0] : 0.f;
+  const size_t HW = (size_t)A.num_pixels;
+  const float hw = (float)A.num_pixels;
+  const float go = A.grad_out ? A.grad_out[0] : 1.f;
+  const float kc = go * A.w_rgb / (3.f * hw), kd = go * A.w_depth / hw;
+  float sc = 0.f, sd = 0.f, ga = 0.f, gb = 0.f;
+  for (size_t p = (size_t)blockIdx.x * kLossBlock + threadIdx.x; p < HW; p += (size_t)gridDim.x * kLossBlock) {
+    const float m = A.mask ? A.mask[p] : 1.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float im = A.image[c * HW + p];
+      const float r = m * (gain * im + bias - A.gt[c * HW + p]);
+      sc += fabsf(r);
+      const float g = kc * m * sgn(r);
+      A.grad_image[c * HW + p] = g * gain;
+      ga += g * im;
+      gb += g;
+    }
+    if (A.w_depth != 0.f) {
+      const float gdp = A.gt_depth[p];
+      const float dm = (A.depth_mask_threshold < 0.f || gdp > A.depth_mask_threshold) ? 1.f : 0.f;
+      const float r = dm * (A.depth[p] - gdp);
+      sd += fabsf(r);
+      if (A.grad_depth) A.grad_depth[p] = kd * dm * sgn(r);
+    } else if (A.grad_depth) {
+      A.grad_depth[p] = 0.f;
+    }
+  }
+  const float tc = block_sum(sc, s_red);
+  const float td = block_sum(sd, s_red);
+  const float ta = block_sum(ga, s_red);
+  const float tb = block_sum(gb, s_red);
+  if (threadIdx.x == 0) {
+    const int n = gridDim.x;
+    A.partial[blockIdx.x] = tc;
+    A.partial[n + blockIdx.x] = td;
+    A.partial[2 * n + blockIdx.x] = A.apply_exposure ? ta * sgn(a) : 0.f;
+    A.partial[3 * n + blockIdx.x] = A.apply_exposure ? tb : 0.f;
+  }
+}
+
 
 // ---------------------------------------------------------------------------------
 // Keyed pseudo-random permutation of [0, m): invertible rounds (add, odd multiply, xor-shift)
@@ -528,7 +593,9 @@ int32_t mgs_camera_from_pose(const float* T, const float* projection, float* vie
 }
 
 int32_t mgs_pose_adam_step(const mgs_pose_adam_args* a, void* stream) {
-  if (!a || !a->cam_rot_delta || !a->cam_trans_delta || !a->exp_avg || !a->exp_avg_sq || a->step < 1)
+  if (!a || !a->exp_avg || !a->exp_avg_sq || a->step < 1) return MGS_ERR_BAD_ARGUMENT;
+  // a NULL delta pointer skips its group (mapping: keyframes outside the pose window)
+  if ((!a->cam_rot_delta || !a->cam_trans_delta) && !a->loss_partials && !a->exposure_partials && !a->grad_a && !a->grad_b)
     return MGS_ERR_BAD_ARGUMENT;
   if ((a->grad_a && !a->exposure_a) || (a->grad_b && !a->exposure_b)) return MGS_ERR_BAD_ARGUMENT;
   launch("pose_adam_update", k_pose_adam_update, dim3(1), dim3(512), (hipStream_t)stream, *a);
@@ -556,6 +623,19 @@ int32_t mgs_mapping_loss_backward(const mgs_mapping_loss_args* a, void* stream) 
   launch("map_loss_bwd", k_map_loss_bwd, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a);
   if (a->grad_a || a->grad_b)   // exposure gradients are the only consumers of the partial sums
     launch("map_loss_bwd_fin", k_map_loss_bwd_finish, dim3(1), dim3(kLossBlock), (hipStream_t)stream, *a, nb);
+  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+}
+
+int32_t mgs_mapping_loss_partial_count(int64_t num_pixels) { return 4 * loss_blocks(num_pixels); }
+
+// Single-pass form used by mgs_mapping_view_iteration; partial = [4][*nblk_out].
+int32_t mgs_mapping_loss_fused(const mgs_mapping_loss_args* a, int32_t* nblk_out, void* stream) {
+  if (!a || !a->image || !a->gt || !a->partial || !a->grad_image || a->num_pixels < 1) return MGS_ERR_BAD_ARGUMENT;
+  if (a->apply_exposure && (!a->exposure_a || !a->exposure_b)) return MGS_ERR_BAD_ARGUMENT;
+  if (a->w_depth != 0.f && (!a->depth || !a->gt_depth || !a->grad_depth)) return MGS_ERR_BAD_ARGUMENT;
+  const int nb = loss_blocks(a->num_pixels);
+  launch("map_loss_fused", k_map_loss_fused, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a);
+  if (nblk_out) *nblk_out = nb;
   return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
 }
 

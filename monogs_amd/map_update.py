@@ -79,7 +79,7 @@ class FusedGaussianAdam:
                                                     _stream(dev)), "mgs_adam_step_multi")
 
 
-def _rebuild(model, plan: _cabi.MapPlanArgs, totals, noise: Optional[torch.Tensor]):
+def _rebuild(model, plan: _cabi.MapPlanArgs, totals, noise: Optional[torch.Tensor], generator=None):
     """Apply a counted plan: emit the row map, gather every per-Gaussian tensor, swap the
     new tensors into the model and its optimiser."""
     dev = model._xyz.device
@@ -92,7 +92,7 @@ def _rebuild(model, plan: _cabi.MapPlanArgs, totals, noise: Optional[torch.Tenso
     _cabi.check(lib.mgs_map_plan_emit(C.byref(plan), _stream(dev)), "mgs_map_plan_emit")
     if n_par > 0:
         if noise is None:
-            noise = torch.randn(2 * n_sel, 3, device=dev)      # one draw per selected Gaussian (:608-609)
+            noise = torch.randn(2 * n_sel, 3, device=dev, generator=generator)   # one draw per selected Gaussian (:608-609)
         noise = noise.to(dev, torch.float32).contiguous()
         assert noise.shape == (2 * n_sel, 3)
 
@@ -164,10 +164,10 @@ def _plan(model, dev, n):
 
 
 @torch.no_grad()
-def densify_and_prune(model, max_grad, min_opacity, extent, max_screen_size, noise=None):
+def densify_and_prune(model, max_grad, min_opacity, extent, max_screen_size, noise=None, generator=None):
     """GaussianModel.densify_and_prune (gaussian_model.py:674-691).  `noise` ([2*n_selected, 3]
     unit normals, one row per split child in the reference's repeat order) replaces the
-    reference's torch.normal draw, for reproducible tests."""
+    reference's torch.normal draw, for reproducible tests; `generator` seeds the draw instead."""
     dev = model._xyz.device
     n = int(model._xyz.shape[0])
     if n == 0:
@@ -183,7 +183,7 @@ def densify_and_prune(model, max_grad, min_opacity, extent, max_screen_size, noi
     plan.big_extent = float(0.1 * extent) if max_screen_size else -1.0
     _cabi.check(_cabi.lib().mgs_map_plan_count(C.byref(plan), _stream(dev)), "mgs_map_plan_count")
     totals = keep[2].tolist()                      # the one host sync of the rebuild
-    rows, _ = _rebuild(model, plan, totals, noise)
+    rows, _ = _rebuild(model, plan, totals, noise, generator)
     # densification_postfix (:591-594): statistics restart from zero for every Gaussian
     model.xyz_gradient_accum = torch.zeros(rows, 1, device=dev)
     model.denom = torch.zeros(rows, 1, device=dev)

@@ -24,9 +24,12 @@ class ViewCamera(nn.Module):
     """The subset of utils/camera_utils.py:Camera (:10-108) the loop bodies touch."""
 
     def __init__(self, uid, image, T_w2c, projection_matrix, fovx, fovy, H, W, device,
-                 gt_depth=None):
+                 gt_depth=None, intrinsics=None):
         super().__init__()
         self.uid, self.device = uid, device
+        if intrinsics is None:      # pinhole with a centred principal point, from the field of view
+            intrinsics = (W / (2 * math.tan(0.5 * fovx)), H / (2 * math.tan(0.5 * fovy)), 0.5 * W, 0.5 * H)
+        self.fx, self.fy, self.cx, self.cy = (float(v) for v in intrinsics)
         self.T = T_w2c.to(device=device, dtype=torch.float32).clone()
         self.original_image = image.to(device)
         self.FoVx, self.FoVy, self.image_height, self.image_width = fovx, fovy, H, W
