@@ -55,15 +55,15 @@ __device__ __forceinline__ int pair_slot_base(const KP& P, int idx) {
 }
 
 // ---------------------------------------------------------------------------------
-// Blend backward, segment-parallel.  One wave per (tile, kSeg-splat segment) work item,
-// FOUR pixels per lane, one in each 8x8 quadrant of the tile.  The lane that stages a splat
+// Blend backward, item-parallel.  One wave per work item = kItemSegs consecutive kSeg-splat
+// segments of one tile, FOUR pixels per lane, one in each 8x8 quadrant of the tile.  The lane that stages a splat
 // also evaluates the culling bound on the four quadrant boxes; the wave then visits, per
 // splat, only the quadrants that can be reached (wave-uniform scalar bit tests on ballot masks).
 // The quadrant body is written on float2 operands so that it maps onto v_pk_{add,mul,fma}_f32
 // (measured on gfx950: a packed FMA issues in about 1.25x the time of a scalar one).  The forward
 // checkpointed the per-pixel blend state (T, prefix colour F) in front of every segment, so items
-// are independent: no serial chain over a tile's whole list, ~D/kSeg equal-sized items instead of
-// T ragged ones.
+// are independent: no serial chain over a tile's whole list, ~D/kItem similar-sized items instead
+// of T ragged ones.
 //
 // Front-to-back replay inside the segment.  With S = (C_final + T_final bg) - F_i (colour
 // still to come behind splat i, background included) the derivative of the pixel w.r.t. the
@@ -88,7 +88,7 @@ constexpr float kLog2eB = 1.4426950408889634f;
 // NULL).  dL/dtau needs the mean / conic / depth sums only, so the colour and opacity sums are
 // not formed and six values instead of ten are reduced per splat.
 template <bool SKETCH, bool JONLY = false, bool POSE = false>
-__global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
+__global__ __launch_bounds__(64, SKETCH ? 4 : (POSE ? 5 : 6)) void k_blend_bwd(KP P, KB B) {
   static_assert(SKETCH || !JONLY, "JONLY is a sketch-mode variant");
   static_assert(!(SKETCH && POSE), "POSE is a plain-mode variant");
   static_assert(kSeg == 64, "one staged record per lane");
@@ -97,20 +97,21 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
   __shared__ float4 s_coef[SKETCH ? kSeg : 1][9];   // per splat: 6 features x 6 tau components
   const int item = xcd_remap<kBwdChunk>(blockIdx.x), lane = threadIdx.x;
   if (item >= min(P.seg_offset[P.T], P.max_segs)) return;
-  // One 16-B record per segment (written by the tile sort) instead of a chain of dependent
-  // loads: tile, index of the segment's first key, number of splats, position in the tile's list.
+  // One 16-B record per item (written by the tile sort) instead of a chain of dependent loads:
+  // tile, index of the item's first key, number of splats (<= kItem), position in the tile's list.
   const int4 sr = P.seg_rec[item];
   const int tile = sr.x, k0 = sr.y, nb = sr.z, base = sr.w;
   if (nb <= 0) return;
+  __builtin_assume(nb <= kItem);
   const int tx = tile % P.grid_x, ty = tile / P.grid_x;
   // Pixel q of this lane lies in QUADRANT q of the tile: (qx + 8 (q & 1), qy + 8 (q >> 1)).
   const int qx = tx * kTile + (lane & 7), qy = ty * kTile + (lane >> 3);
   const size_t HW = (size_t)P.W * P.H;
-  // the key of this lane's splat is requested first; the ~60 per-pixel loads below are issued
-  // while it is in flight, and the record gather that depends on it comes after them
-  const unsigned int lo = lane < nb ? (unsigned int)P.keys[k0 + lane] : 0u;
+  // the key of this lane's first splat is requested first; the ~60 per-pixel loads below are
+  // issued while it is in flight, and the record gather that depends on it comes after them
+  unsigned int lo_next = lane < nb ? (unsigned int)P.keys[k0 + lane] : 0u;
 
-  // ---- per-pixel state ----------------------------------------------------------------------
+  // ---- per-pixel state (loaded once per item, carried across its segments in registers) ------
   // T (transmittance in front of the next splat) and the scalar
   //   gS = sum_ch dL/dC_ch * S_ch,   S = (C_final + T_final * bg) - F
   // (S = colour/depth still to come BEHIND the splats visited so far, background included,
@@ -120,101 +121,56 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
   float g0[4], g1[4], g2[4], gd[4], T[4], gS[4];
   const float bg0 = P.bg[0], bg1 = P.bg[1], bg2 = P.bg[2];
   const float* ck = (base > 0) ? P.ckpt + (size_t)item * (5 * 256) : nullptr;
+  // Last list position that still contributes anywhere in each quadrant (stored by the forward's
+  // quadrant waves; a quadrant outside the image was never rendered).  A splat behind it cannot
+  // contribute in that quadrant - the forward had stopped visiting the saturated quadrant - so its
+  // reach bit is dropped at staging time, and a quadrant that is saturated in front of this whole
+  // item loads nothing at all.
+  int qlast[4];
+  {
+    const int4 ql = *reinterpret_cast<const int4*>(P.quad_last + 4 * tile);    // wave-uniform: one scalar load
+    qlast[0] = ql.x; qlast[1] = ql.y; qlast[2] = ql.z; qlast[3] = ql.w;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (tx * kTile + 8 * (q & 1) >= P.W || ty * kTile + 8 * (q >> 1) >= P.H) qlast[q] = 0;
+  }
+  const size_t TQ = (size_t)256 * P.T;
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const int px = qx + 8 * (q & 1), py = qy + 8 * (q >> 1);
-    float c0 = 0.f, c1 = 0.f, c2 = 0.f, cd = 0.f;
     g0[q] = g1[q] = g2[q] = gd[q] = 0.f;
     last[q] = 0;
+    T[q] = 0.f;
+    gS[q] = 0.f;
+    if (qlast[q] <= base) continue;                   // wave-uniform: quadrant done before this item
+    const size_t qi = (size_t)tile * 256 + 64 * q + lane;     // quadrant-major: coalesced
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, cd = 0.f;
     T[q] = 1.f;
+    last[q] = P.n_contrib[qi];
     if (px < P.W && py < P.H) {
       const size_t pix = (size_t)py * P.W + px;
-      last[q] = P.n_contrib[pix];
       g0[q] = B.grad_color[pix]; g1[q] = B.grad_color[HW + pix]; g2[q] = B.grad_color[2 * HW + pix];
       if (B.grad_depth) gd[q] = B.grad_depth[pix];
-      const float tf = P.final_T[pix];
-      c0 = P.final_C[pix] + tf * bg0; c1 = P.final_C[HW + pix] + tf * bg1;
-      c2 = P.final_C[2 * HW + pix] + tf * bg2;
-      cd = P.final_C[3 * HW + pix];
+    }
+    {
+      const float tf = P.final_T[qi];
+      c0 = P.final_C[qi] + tf * bg0; c1 = P.final_C[TQ + qi] + tf * bg1;
+      c2 = P.final_C[2 * TQ + qi] + tf * bg2;
+      cd = P.final_C[3 * TQ + qi];
     }
     if (ck) {
-      const int p = (py - ty * kTile) * kTile + (px - tx * kTile);   // pixel index in the tile
+      const int p = 64 * q + lane;
       T[q] = ck[p]; c0 -= ck[256 + p]; c1 -= ck[512 + p]; c2 -= ck[768 + p]; cd -= ck[1024 + p];
     }
     gS[q] = g0[q] * c0 + g1[q] * c1 + g2[q] * c2 + gd[q] * cd;
-    // a pixel whose list ended in front of this segment contributes nothing here, and the
+    // a pixel whose list ended in front of this item contributes nothing here, and the
     // forward stops checkpointing a quadrant once all its pixels are saturated: never let
     // that (unwritten) state into the arithmetic
     if (last[q] <= base) { T[q] = 0.f; gS[q] = 0.f; }
   }
-  // Last list position that still contributes anywhere in each quadrant (wave maxima of
-  // n_contrib).  A splat behind it cannot contribute in that quadrant - the forward had stopped
-  // visiting the saturated quadrant - so its reach bit is dropped at staging time and the
-  // quadrant body is never entered for it.
-  int qlast[4];
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    int v = last[q];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
-    qlast[q] = v;
-  }
-  // does any pixel of the tile reach this segment?
-  const bool dead = max(max(qlast[0], qlast[1]), max(qlast[2], qlast[3])) <= base;
+  const int tile_last = max(max(qlast[0], qlast[1]), max(qlast[2], qlast[3]));
 
-  // ---- stage the segment's records (one per lane): slot, raw conic, quadrant reach mask ---
-  int slot = -1;
-  unsigned long long mq[4];
-  {
-    unsigned int mask4 = 0;
-    if (lane < nb) {
-      const unsigned int id = P.pack ? lo >> kPackBits : lo;
-      if constexpr (!JONLY) {
-        slot = pair_slot_base(P, (int)id) + (int)(P.pack ? (lo & ((1u << kPackBits) - 1u)) : P.payload[k0 + lane]);
-        // slots are Gaussian-major positions among ALL pairs: with an undersized capacity some
-        // lie beyond the pair_grad buffer (the forward was incomplete anyway) - never touch them
-        if (slot >= P.cap) slot = -1;
-      }
-      if (!dead) {
-        const float4* src = reinterpret_cast<const float4*>(P.rec + id);
-        const float4 qa = src[0], qb = src[1];
-        const float4 q2 = src[2];
-        s_r0[lane] = make_float4(qa.x, qa.y, -0.5f * kLog2eB * qb.x, -kLog2eB * qb.y);
-        s_r1[lane] = make_float4(-0.5f * kLog2eB * qb.z, qa.w, q2.x, q2.y);   // (C', opacity, r, g)
-        s_r2[lane] = make_float2(q2.z, qa.z);                                  // (b, depth)
-        if constexpr (SKETCH) {
-          const float4* cj = reinterpret_cast<const float4*>(B.splat_jac + (size_t)id * 36);
-#pragma unroll
-          for (int i = 0; i < 9; i++) s_coef[lane][i] = cj[i];
-        }
-        const float qmax = splat_qmax(qa.w);
-        const float Wm = (float)(P.W - 1), Hm = (float)(P.H - 1);
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const float x0 = (float)(tx * kTile + 8 * (q & 1)), y0 = (float)(ty * kTile + 8 * (q >> 1));
-          if (base + lane < qlast[q] && x0 <= Wm && y0 <= Hm &&
-              box_reachable(qa.x, qa.y, qb.x, qb.y, qb.z, qmax, x0, y0, fminf(x0 + 7.f, Wm), fminf(y0 + 7.f, Hm)))
-            mask4 |= 1u << q;
-        }
-      }
-    }
-    // quadrant reach masks of the whole segment as four wave-uniform 64-bit words (bit j = splat
-    // j reaches quadrant q): they live in SGPRs, so the walk below skips unreachable splats and
-    // quadrants with scalar bit tests - no LDS round trip in front of every splat
-#pragma unroll
-    for (int q = 0; q < 4; q++) mq[q] = __builtin_amdgcn_ballot_w64((mask4 >> q) & 1u);
-  }
-  if (dead) {
-    if (!JONLY && slot >= 0) {
-      float4* dst = B.pair_grad + (size_t)slot * 3;
-      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      dst[0] = z; dst[1] = z; dst[2] = z;
-    }
-    return;
-  }
-  __syncthreads();
-
-  // sketch mode: per-pixel pose-Jacobian rows of this segment, as pairs (tau 0,1) (2,3) (4,5)
+  // sketch mode: per-pixel pose-Jacobian rows of this item, as pairs (tau 0,1) (2,3) (4,5)
   v2f J2[SKETCH ? 4 : 1][3];
 #pragma unroll
   for (int q = 0; q < (SKETCH ? 4 : 1); q++)
@@ -240,11 +196,14 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
     G2d[q] = v2f{g2[q], gd[q]};
   }
 
+  // per-segment state of the walk
+  int slot = -1, sub_base = base;
+  unsigned long long mq[4] = {0ull, 0ull, 0ull, 0ull};
   unsigned long long written = 0ull;
-  // one splat: (u, v, bd2) = its staged record, m = the quadrants it reaches
+  // one splat: (u, v, bd2) = its staged record; mq = the quadrants the segment's splats reach
   auto visit = [&](int j, const float4 u, const float4 v, const float2 bd2) {
     const v2f mu = {u.x, u.y}, RG = {v.z, v.w}, BD = {bd2.x, bd2.y};
-    const int idx = base + j;
+    const int idx = sub_base + j;
     const v2f* cf2 = reinterpret_cast<const v2f*>(&s_coef[SKETCH ? j : 0][0]);   // [feature][tau pair]
     // pixel sums of this splat: S1 | (Sx, Sy) | (Sxx, Sxy) | Syy | (Rr, Rg) | (Rb, Rd)
     float r0 = 0.f, r5 = 0.f;
@@ -322,35 +281,100 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
       written |= 1ull << j;
     }
   };
-  // Walk over the splats that reach any quadrant (set bits of the union mask), two-way unrolled
-  // with the NEXT splat's record prefetched from LDS above the arithmetic of the current one, so
-  // that no LDS latency sits between two splats and no registers rotate.
-  unsigned long long todo = mq[0] | mq[1] | mq[2] | mq[3];
+
+  // ---- the item's segments, 64 splats (one staged record per lane) at a time ------------------
+  for (int sub = 0; sub < nb; sub += kSeg) {
+    const int nsub = min(kSeg, nb - sub);
+    sub_base = base + sub;
+    const unsigned int lo = lo_next;
+    // key of the NEXT segment: in flight while this one is staged and walked
+    lo_next = (sub + kSeg + lane < nb) ? (unsigned int)P.keys[k0 + sub + kSeg + lane] : 0u;
+    // does any pixel of the tile reach this segment?  (if not, none of the later ones either,
+    // but their pairs still need their zero records)
+    const bool dead = tile_last <= sub_base;
+    // stage the segment's records (one per lane): slot, raw conic, quadrant reach mask
+    slot = -1;
+    unsigned int mask4 = 0;
+    if (sub > 0) __syncthreads();     // single-wave workgroup: orders the LDS reuse, no hardware barrier
+    if (lane < nsub) {
+      const unsigned int id = P.pack ? lo >> kPackBits : lo;
+      if constexpr (!JONLY) {
+        slot = pair_slot_base(P, (int)id) + (int)(P.pack ? (lo & ((1u << kPackBits) - 1u)) : P.payload[k0 + sub + lane]);
+        // slots are Gaussian-major positions among ALL pairs: with an undersized capacity some
+        // lie beyond the pair_grad buffer (the forward was incomplete anyway) - never touch them
+        if (slot >= P.cap) slot = -1;
+      }
+      if (!dead) {
+        const float4* src = reinterpret_cast<const float4*>(P.rec + id);
+        const float4 qa = src[0], qb = src[1];
+        const float4 q2 = src[2];
+        s_r0[lane] = make_float4(qa.x, qa.y, -0.5f * kLog2eB * qb.x, -kLog2eB * qb.y);
+        s_r1[lane] = make_float4(-0.5f * kLog2eB * qb.z, qa.w, q2.x, q2.y);   // (C', opacity, r, g)
+        s_r2[lane] = make_float2(q2.z, qa.z);                                  // (b, depth)
+        if constexpr (SKETCH) {
+          const float4* cj = reinterpret_cast<const float4*>(B.splat_jac + (size_t)id * 36);
+#pragma unroll
+          for (int i = 0; i < 9; i++) s_coef[lane][i] = cj[i];
+        }
+        const float qmax = splat_qmax(qa.w);
+        const float Wm = (float)(P.W - 1), Hm = (float)(P.H - 1);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float x0 = (float)(tx * kTile + 8 * (q & 1)), y0 = (float)(ty * kTile + 8 * (q >> 1));
+          if (sub_base + lane < qlast[q] && x0 <= Wm && y0 <= Hm &&
+              box_reachable(qa.x, qa.y, qb.x, qb.y, qb.z, qmax, x0, y0, fminf(x0 + 7.f, Wm), fminf(y0 + 7.f, Hm)))
+            mask4 |= 1u << q;
+        }
+      }
+    }
+    written = 0ull;
+    if (!dead) {
+      // quadrant reach masks of the whole segment as four wave-uniform 64-bit words (bit j = splat
+      // j reaches quadrant q): they live in SGPRs, so the walk below skips unreachable splats and
+      // quadrants with scalar bit tests - no LDS round trip in front of every splat
+#pragma unroll
+      for (int q = 0; q < 4; q++) mq[q] = __builtin_amdgcn_ballot_w64((mask4 >> q) & 1u);
+      __syncthreads();
+      // Walk over the splats that reach any quadrant (set bits of the union mask), two-way
+      // unrolled with the NEXT splat's record prefetched from LDS above the arithmetic of the
+      // current one, so that no LDS latency sits between two splats and no registers rotate.
+      unsigned long long todo = mq[0] | mq[1] | mq[2] | mq[3];
 #if defined(MGS_ABL) && MGS_ABL == 4
-  todo = 0ull;
+      todo = 0ull;
 #endif
-  if (todo != 0ull) {
-    int j0 = __builtin_ctzll(todo);
-    float4 u0 = s_r0[j0], v0 = s_r1[j0];
-    float2 w0 = s_r2[j0];
-    while (true) {
-      todo &= todo - 1ull;
-      const int j1 = __builtin_ctzll(todo) & 63;       // todo == 0: harmless read of slot 63
-      const float4 u1 = s_r0[j1], v1 = s_r1[j1];
-      const float2 w1 = s_r2[j1];
-      __builtin_amdgcn_sched_barrier(0);               // keep the prefetch above the arithmetic
-      visit(j0, u0, v0, w0);
-      if (todo == 0ull) break;
-      todo &= todo - 1ull;
-      j0 = __builtin_ctzll(todo) & 63;
-      u0 = s_r0[j0]; v0 = s_r1[j0]; w0 = s_r2[j0];
-      __builtin_amdgcn_sched_barrier(0);
-      visit(j1, u1, v1, w1);
-      if (todo == 0ull) break;
+      if (todo != 0ull) {
+        int j0 = __builtin_ctzll(todo);
+        float4 u0 = s_r0[j0], v0 = s_r1[j0];
+        float2 w0 = s_r2[j0];
+        while (true) {
+          todo &= todo - 1ull;
+          const int j1 = __builtin_ctzll(todo) & 63;       // todo == 0: harmless read of slot 63
+          const float4 u1 = s_r0[j1], v1 = s_r1[j1];
+          const float2 w1 = s_r2[j1];
+          __builtin_amdgcn_sched_barrier(0);               // keep the prefetch above the arithmetic
+          visit(j0, u0, v0, w0);
+          if (todo == 0ull) break;
+          todo &= todo - 1ull;
+          j0 = __builtin_ctzll(todo) & 63;
+          u0 = s_r0[j0]; v0 = s_r1[j0]; w0 = s_r2[j0];
+          __builtin_amdgcn_sched_barrier(0);
+          visit(j1, u1, v1, w1);
+          if (todo == 0ull) break;
+        }
+      }
+    }
+    // splats of the segment that no pixel reached: zero record
+    if (!JONLY && slot >= 0 && !((written >> lane) & 1ull)) {
+      float4* dst = B.pair_grad + (size_t)slot * 3;
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      dst[0] = z; dst[1] = z; dst[2] = z;
     }
   }
+#if defined(MGS_ABL)
+  if (T[0] == 123.456f && slot >= 0) B.pair_grad[(size_t)slot * 3].x = T[0] + T[1] + T[2] + T[3] + gS[0] + gS[1] + gS[2] + gS[3];
+#endif
   if constexpr (SKETCH) {
-    // pixel rows of different segments of a tile meet in pix_jac: float atomics, planar
+    // pixel rows of different items of a tile meet in pix_jac: float atomics, planar
     // [6][H*W] so a wave instruction covers 8-pixel runs of contiguous addresses
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -361,15 +385,6 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : 6) void k_blend_bwd(KP P, KB B) {
         for (int t = 0; t < 6; t++) atomicAdd(&B.pix_jac[(size_t)t * HW + pix], (t & 1) ? J2[q][t >> 1].y : J2[q][t >> 1].x);
       }
     }
-  }
-#if defined(MGS_ABL)
-  if (T[0] == 123.456f && slot >= 0) B.pair_grad[(size_t)slot * 3].x = T[0] + T[1] + T[2] + T[3] + gS[0] + gS[1] + gS[2] + gS[3];
-#endif
-  // splats of the segment that no pixel reached: zero record
-  if (!JONLY && slot >= 0 && !((written >> lane) & 1ull)) {
-    float4* dst = B.pair_grad + (size_t)slot * 3;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    dst[0] = z; dst[1] = z; dst[2] = z;
   }
 }
 

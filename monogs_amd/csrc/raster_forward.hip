@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void k_scan_write(KP P) {
 
 // ---------------------------------------------------------------------------------
 // Exclusive scans of the T tile counts (-> tile_offset, D) and of the per-tile segment
-// counts ceil(n_t / kSeg) (-> seg_offset) by one 1024-thread workgroup.
+// backward item counts ceil(n_t / kItem) (-> seg_offset) by one 1024-thread workgroup.
 __device__ __forceinline__ void tile_scan_body(const KP& P, int nbin, int* s_sum, int* s_seg) {
   const int tid = threadIdx.x;
   if (nbin > 0) {   // exclusive scan of the binning blocks' pair totals (nbin <= 1024)
@@ -323,7 +323,7 @@ __device__ __forceinline__ void tile_scan_body(const KP& P, int nbin, int* s_sum
   for (int i = lo; i < hi; i++) {
     const int c = __hip_atomic_load(&P.tile_count[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     local += c;
-    lseg += (c + kSeg - 1) / kSeg;
+    lseg += (c + kItem - 1) / kItem;
   }
   s_sum[tid] = local;
   s_seg[tid] = lseg;
@@ -342,7 +342,7 @@ __device__ __forceinline__ void tile_scan_body(const KP& P, int nbin, int* s_sum
     P.tile_offset[i] = run;
     P.seg_offset[i] = rseg;
     run += c;
-    rseg += (c + kSeg - 1) / kSeg;
+    rseg += (c + kItem - 1) / kItem;
   }
   if (tid == 1023) {
     P.tile_offset[P.T] = s_sum[1023];
@@ -555,13 +555,13 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(KP P) {
   const int n_all = end - start;                    // as counted by the scans (seg_offset)
   start = min(start, P.cap); end = min(end, P.cap);
   const int n = end - start;
-  if (MIN_N == 0) {   // segment -> tile map for the segment-parallel backward
-    // EVERY segment the scan counted gets a record - also those cut off by an undersized pair
+  if (MIN_N == 0) {   // item -> tile map for the item-parallel backward
+    // EVERY item the scan counted gets a record - also those cut off by an undersized pair
     // capacity (0 splats), so that the backward never reads an unwritten record
-    const int s0 = P.seg_offset[tile], ns = (n_all + kSeg - 1) / kSeg;
+    const int s0 = P.seg_offset[tile], ns = (n_all + kItem - 1) / kItem;
     for (int i = tid; i < ns; i += THREADS)
       if (s0 + i < P.max_segs)
-        P.seg_rec[s0 + i] = make_int4(tile, min(start + i * kSeg, P.cap), max(0, min(kSeg, n - i * kSeg)), i * kSeg);
+        P.seg_rec[s0 + i] = make_int4(tile, min(start + i * kItem, P.cap), max(0, min(kItem, n - i * kItem)), i * kItem);
   }
   if (n <= 1 || n <= MIN_N || (MIN_N == 0 && n > CAP)) continue;   // workgroup-uniform
   unsigned long long* gk = P.keys + start;
@@ -599,10 +599,10 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(KP P) {
 // -0.5*log2(e) (a pixel evaluation is a few FMAs + one v_exp_f32) and the wave visits them
 // in list order by scanning the ballot mask.  Global loads are software-pipelined: ids two
 // segments ahead, records one segment ahead, so the id -> record dependent latency hides
-// under the previous segment's arithmetic.  In front of every segment the per-pixel blend
-// state (T, C, D) is checkpointed for the segment-parallel backward; a quadrant whose
-// pixels are all saturated stops writing checkpoints (the backward never reads the state
-// of a pixel whose n_contrib lies in front of the segment).
+// under the previous segment's arithmetic.  In front of every backward item (kItem splats) the
+// per-pixel blend state (T, C, D) is checkpointed for the item-parallel backward; a quadrant
+// whose pixels are all saturated stops writing checkpoints (the backward never reads the state
+// of a pixel whose n_contrib lies in front of the item).
 constexpr float kLog2e = 1.4426950408889634f;
 typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int kFwdChunk = 4;       // the four quadrants of a tile share an XCD (same records)
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
   const int qx0 = tx * kTile + 8 * (quad & 1), qy0 = ty * kTile + 8 * (quad >> 1);
   if (qx0 >= P.W || qy0 >= P.H) return;                  // quadrant outside the image
   const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
-  const int ptile = (py - ty * kTile) * kTile + (px - tx * kTile);     // pixel index in the tile
+  const int ptile = quad * 64 + lane;                    // pixel index in the tile, quadrant-major
   const bool inside = px < P.W && py < P.H;
   int start = P.tile_offset[tile], end = P.tile_offset[tile + 1];
   start = min(start, P.cap); end = min(end, P.cap);
@@ -683,8 +683,8 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
     const float4 na = src1[0], nb4 = src1[1], nc = src1[2];
     id_n1 = fwd_load_id(P, start, n, base + 2 * kSeg + lane);
 
-    if (base > 0) {   // checkpoint: state in front of this segment
-      const int sg = seg0 + base / kSeg;
+    if (base > 0 && base % kItem == 0) {   // checkpoint: state in front of this backward item
+      const int sg = seg0 + base / kItem;
       if (sg < P.max_segs) {
         float* ck = P.ckpt + (size_t)sg * (5 * 256) + ptile;
         ck[0] = T; ck[256] = C01.x; ck[512] = C01.y; ck[768] = C2D.x; ck[1024] = C2D.y;
@@ -765,13 +765,20 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
     if (__builtin_amdgcn_ballot_w64(live != 0.f) == 0ull) break;   // quadrant saturated
     cid = nid; ca = na; cb = nb4; cc = nc;
   }
+  {   // state for the backward, quadrant-major (coalesced); lanes outside the image hold last = 0
+    const size_t TQ = (size_t)256 * P.T, qi = (size_t)tile * 256 + ptile;
+    P.final_T[qi] = T;
+    P.n_contrib[qi] = last;
+    P.final_C[qi] = C01.x; P.final_C[TQ + qi] = C01.y;
+    P.final_C[2 * TQ + qi] = C2D.x; P.final_C[3 * TQ + qi] = C2D.y;
+    int m = last;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
+    if (lane == 0) P.quad_last[4 * tile + quad] = m;
+  }
   if (inside) {
     const size_t HW = (size_t)P.W * P.H;
     const size_t pix = (size_t)py * P.W + px;
-    P.final_T[pix] = T;
-    P.n_contrib[pix] = last;
-    P.final_C[pix] = C01.x; P.final_C[HW + pix] = C01.y;
-    P.final_C[2 * HW + pix] = C2D.x; P.final_C[3 * HW + pix] = C2D.y;
     P.out_color[pix] = C01.x + T * P.bg[0];
     P.out_color[HW + pix] = C01.y + T * P.bg[1];
     P.out_color[2 * HW + pix] = C2D.x + T * P.bg[2];

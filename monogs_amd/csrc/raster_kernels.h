@@ -27,16 +27,21 @@ struct KP {
   int* tile_offset;
   int* tile_cursor;
   int* bin_table;          // kBinBlocks x T per-block tile histograms / bases
-  float* final_T;
-  float* final_C;          // [4][H*W] colour (without background) and depth at the end of the list
-  int* n_contrib;
-  int* seg_offset;         // T+1: exclusive scan of ceil(n_t / kSeg)
+  // per-pixel results of the forward that only the backward reads, in QUADRANT-MAJOR order:
+  // entry (tile * 4 + quadrant) * 64 + lane, lane = (y & 7) * 8 + (x & 7) - the order in which a
+  // quadrant wave of either blend kernel holds its pixels, so every access is one coalesced 256-B run
+  float* final_T;          // [256 T]
+  float* final_C;          // [4][256 T] colour (without background) and depth at the end of the list
+  int* n_contrib;          // [256 T]
+  int* quad_last;          // [4 T] max of n_contrib over the quadrant: the list position behind which the
+                           // quadrant is saturated (the backward skips it from there on)
+  int* seg_offset;         // T+1: exclusive scan of ceil(n_t / kItem): first backward item of a tile
   int* counters;
   // bins workspace
   unsigned long long* keys;
   unsigned int* payload;
-  int4* seg_rec;           // segment -> (tile, first key index, splats in the segment, base)
-  float* ckpt;             // per segment: [5][256] blend state (T, C0, C1, C2, D) before its first splat
+  int4* seg_rec;           // backward item -> (tile, first key index, splats in the item, position in the list)
+  float* ckpt;             // per item: [5][256] blend state (T, C0, C1, C2, D) before its first splat
   int max_segs;
   // forward outputs
   float *out_color, *out_depth, *out_opacity;
@@ -91,7 +96,7 @@ inline uint64_t align_up(uint64_t v) { return (v + kAlign - 1) / kAlign * kAlign
 
 struct Layout {
   uint64_t rec, pair_count, pair_off, block_prefix, scan_tmp, tile_count, tile_offset, tile_cursor, bin_table, final_T, final_C,
-      n_contrib, seg_offset, counters, geom_bytes;
+      n_contrib, quad_last, seg_offset, counters, geom_bytes;
   uint64_t keys, payload, seg_rec, ckpt, max_segs, bins_bytes;
   uint64_t pair_grad, tau_partial, bwd_bytes;
   uint64_t pix_jac, splat_jac, sketch_bytes;
@@ -104,7 +109,15 @@ constexpr int kPreBlock = 256;
 // 12 B.  The order is unchanged: a Gaussian occurs once per tile, so (depth, id) is already unique.
 constexpr int kPackBits = 12;
 constexpr int kPackMaxN = 1 << 20;
-constexpr int kSeg = 64;            // splats per blend segment (checkpoint interval)
+constexpr int kSeg = 64;            // splats staged at a time by the blend kernels (one record per lane)
+// A backward work item is kItemSegs consecutive segments of one tile (the per-pixel state is loaded
+// once per item and carried across its segments in registers; the forward checkpoints the blend
+// state in front of every item).  Measured on SYN-C (profiles/r02_item_size_experiment.txt):
+// 1 segment per item 136 us, 2: 160 us, 4: 192 us - larger items cut the per-item loads but leave
+// fewer items (3.7k at 4) than the chip has wave slots (~5.6k), and the kernel then runs at the
+// latency of one long item instead of at the chip's throughput.  So: 1.
+constexpr int kItemSegs = 1;
+constexpr int kItem = kSeg * kItemSegs;
 constexpr int kBinBlocks = 512;    // workgroups of the LDS-privatised binning passes
 constexpr int kBinThreads = 1024;
 constexpr int kBinMaxTilesLds = 12288;   // T above this falls back to global atomics
@@ -128,16 +141,17 @@ inline Layout make_layout(const mgs_raster_shape& s) {
   L.tile_offset = o; o = align_up(o + (T + 1) * 4);
   L.tile_cursor = o; o = align_up(o + T * 4);
   L.bin_table = o; o = align_up(o + (uint64_t)kBinBlocks * T * 4);
-  L.final_T = o; o = align_up(o + HW * 4);
-  L.final_C = o; o = align_up(o + HW * 16);
-  L.n_contrib = o; o = align_up(o + HW * 4);
+  L.final_T = o; o = align_up(o + T * 256 * 4);
+  L.final_C = o; o = align_up(o + T * 256 * 16);
+  L.n_contrib = o; o = align_up(o + T * 256 * 4);
+  L.quad_last = o; o = align_up(o + T * 4 * 4);
   L.seg_offset = o; o = align_up(o + (T + 1) * 4);
   L.counters = o; o = align_up(o + 16);
   L.geom_bytes = o;
   o = 0;
   L.keys = o; o = align_up(o + cap * 8);
   L.payload = o; o = align_up(o + cap * 4);
-  L.max_segs = cap / kSeg + T;
+  L.max_segs = cap / kItem + T;
   L.seg_rec = o; o = align_up(o + L.max_segs * 16);
   L.ckpt = o; o = align_up(o + L.max_segs * 5 * 256 * 4);
   L.bins_bytes = o;

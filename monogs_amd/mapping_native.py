@@ -418,7 +418,7 @@ class NativeMapper:
                 self._step_gaussians(skip=("_opacity",) if reset else ())
                 gaussian_split = gaussian_split or reset
             g.update_learning_rate(self.iteration_count)
-            self.last_loss = self.loss_accum
+            self.last_loss = self.loss_accum.clone()
         return gaussian_split
 
     def _split_generator(self):
@@ -486,5 +486,5 @@ class NativeMapper:
                 g.reset_opacity()
             if not densify:
                 self._step_gaussians(skip=("_opacity",) if reset else ())
-        self.last_loss = self.loss_accum
+        self.last_loss = self.loss_accum.clone()
         return self.occ_aware_visibility.get(kf_idx)

@@ -58,7 +58,7 @@ def update_pose(camera, converged_threshold: float = 1e-4) -> bool:
     whether |tau| fell below the threshold (pose_utils.py:88-98)."""
     with torch.no_grad():
         tau = torch.cat([camera.cam_trans_delta, camera.cam_rot_delta])
-        camera.T = SE3_exp(tau) @ camera.T
+        camera.T.copy_(SE3_exp(tau) @ camera.T)     # in place: native code may hold this buffer's address
         small = bool(torch.dot(tau, tau) < converged_threshold * converged_threshold)
         camera.cam_trans_delta.zero_()
         camera.cam_rot_delta.zero_()

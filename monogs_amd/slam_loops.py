@@ -232,7 +232,7 @@ def tracking_step_second_order(viewpoint, gaussians, background, lambda_, repeat
         b = torch.cat((Sf, torch.zeros(n, device=SJ.device)), dim=0)
         x = torch.linalg.lstsq(A, -b).solution
         # TempCamera.step (slam_frontend.py:49-53): tau = x[:6] = [trans; rot], exposure x[6:8]
-        viewpoint.T = SE3_exp(x[:6]) @ viewpoint.T
+        viewpoint.T.copy_(SE3_exp(x[:6]) @ viewpoint.T)
         viewpoint.exposure_a += x[6]
         viewpoint.exposure_b += x[7]
     return weighted.detach().abs().sum(), x, SJ, Sf

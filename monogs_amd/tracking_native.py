@@ -81,6 +81,10 @@ class NativeTracker:
         f.campos, f.bg, f.geom = self.view.data_ptr(), self.bg.data_ptr(), self.geom.data_ptr()
         f.out_color, f.out_depth, f.out_opacity = self.color.data_ptr(), self.depth.data_ptr(), self.opacity.data_ptr()
         f.radii, f.n_touched = self.radii.data_ptr(), self.n_touched.data_ptr()
+        # sticky high-water mark of the pair count over ALL iterations since the last check: an
+        # overflow in the middle of a run is seen even when the last iteration fits
+        self._d_max = torch.zeros(1, dtype=torch.int32, device=dev)
+        f.pair_count_max = self._d_max.data_ptr()
         _cabi.check(lib.mgs_raster_forward_project(C.byref(f), stream), "mgs_raster_forward_project")
         off = int(sizes.off_counters)
         self._counter = self.geom[off:off + 4].view(torch.int32)
@@ -115,6 +119,8 @@ class NativeTracker:
         self.args = a
         self.t = 0
         self._matrices_fresh = False
+        self._T_ptr = vp.T.data_ptr()
+        self._d_max.zero_()
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
@@ -157,9 +163,11 @@ class NativeTracker:
         residual, sketch-mode backward, damped solve and pose / exposure step, all on the
         device.  Returns lm_state = [lambda, ||residual||_1, 1, converged] (device tensor)."""
         so = self.so_args
+        self._sync_pose_pointer()
         # pointers that _alloc_bins may have replaced since enable_second_order
         so.base.fwd.bins, so.base.bwd = self.args.fwd.bins, self.args.bwd
         so.base.fwd.shape.pair_capacity = self.args.fwd.shape.pair_capacity
+        so.base.adam.T = self.args.adam.T
         self.so_t += 1
         so.key = (self.so_seed * 0x9E3779B97F4A7C15 + self.so_t) & 0xFFFFFFFFFFFFFFFF
         _cabi.check(_cabi.lib().mgs_tracking_iteration_second_order(C.byref(so), self._stream()),
@@ -174,8 +182,24 @@ class NativeTracker:
         a = self.so_accum
         return a[:d], torch.cat((a[3 * d:9 * d].view(d, 6), a[d:3 * d].view(d, 2)), dim=1)
 
+    def _sync_pose_pointer(self):
+        """`viewpoint.T` may have been REBOUND to a new tensor by Python code between two native
+        calls (camera.T = ...): follow it instead of updating a stale buffer, and rebuild the camera
+        matrices.  (In-place writes to T by others are not detectable: call invalidate_matrices().)"""
+        vp = self.vp
+        if vp.T.data_ptr() != self._T_ptr:
+            if not (vp.T.is_contiguous() and vp.T.dtype == torch.float32 and vp.T.device == self.dev):
+                raise RuntimeError("viewpoint.T must stay a contiguous float32 4x4 tensor on the tracker's device")
+            self._T_ptr = vp.T.data_ptr()
+            self.args.adam.T = self._T_ptr
+            self._matrices_fresh = False
+
+    def invalidate_matrices(self):
+        self._matrices_fresh = False
+
     def step(self):
         """Enqueue one iteration; returns the device convergence flag (int32[1])."""
+        self._sync_pose_pointer()
         self.t += 1
         self.args.adam.step = self.t
         self.args.camera_matrices_valid = 1 if self._matrices_fresh else 0
@@ -193,25 +217,60 @@ class NativeTracker:
         return int(self._counter.item())
 
     def check_capacity(self):
-        """True if every iteration so far rendered completely; otherwise grows the workspaces
-        (the caller re-runs the affected iterations - the pose only moves by millimetres per
-        iteration, so a 1.5x margin is not reached in practice)."""
-        D = self.pairs()
-        if D <= self.capacity:
+        """True if EVERY iteration since the last check rendered completely (the forward keeps a
+        sticky maximum of the pair count on the device); otherwise grows the workspaces for the
+        worst count seen and returns False - the caller re-runs the affected iterations (`run`
+        does, from a snapshot of the state)."""
+        worst = int(self._d_max.item())
+        self._d_max.zero_()
+        if worst <= self.capacity:
             return True
-        self._alloc_bins(self.args, int(D * self.capacity_margin))
+        self._alloc_bins(self.args, int(worst * self.capacity_margin))
         return False
 
-    def run(self, max_iters=100, check_every=10):
-        """The reference's loop (slam_frontend.py:493-630): iterate until converged or
-        max_iters; the flag is read back every `check_every` iterations."""
-        it = 0
-        while it < max_iters:
-            for _ in range(min(check_every, max_iters - it)):
-                self.step()
+    def _snapshot(self):
+        vp = self.vp
+        keep = dict(T=vp.T.detach().clone(), a=vp.exposure_a.detach().clone(), b=vp.exposure_b.detach().clone(),
+                    rot=vp.cam_rot_delta.detach().clone(), trans=vp.cam_trans_delta.detach().clone(),
+                    m=self.exp_avg.clone(), v=self.exp_avg_sq.clone(), t=self.t)
+        if hasattr(self, "lm_state"):
+            keep["lm"], keep["so_t"] = self.lm_state.clone(), self.so_t
+        return keep
+
+    def _restore(self, keep):
+        vp = self.vp
+        with torch.no_grad():
+            vp.T.copy_(keep["T"])
+            vp.exposure_a.copy_(keep["a"]); vp.exposure_b.copy_(keep["b"])
+            vp.cam_rot_delta.copy_(keep["rot"]); vp.cam_trans_delta.copy_(keep["trans"])
+            self.exp_avg.copy_(keep["m"]); self.exp_avg_sq.copy_(keep["v"])
+            if "lm" in keep:
+                self.lm_state.copy_(keep["lm"])
+                self.so_t = keep["so_t"]
+        self.t = keep["t"]
+        self.converged.zero_()
+        self._matrices_fresh = False
+
+    def run(self, max_iters=100, check_every=10, second_order_iters=0):
+        """The reference's loop (slam_frontend.py:493-630): first-order iterations until converged
+        or max_iters (the flag is read back every `check_every` iterations), then
+        `second_order_iters` sketched LM iterations (enable_second_order first).  If ANY iteration
+        overflowed the fixed pair capacity, pose, exposure and optimiser state are restored from the
+        snapshot taken on entry, the workspaces grow and the run is repeated: no truncated render ever
+        reaches the result."""
+        keep = self._snapshot()
+        for attempt in range(4):
+            it = 0
+            while it < max_iters:
+                for _ in range(min(check_every, max_iters - it)):
+                    self.step()
+                    it += 1
+                if int(self.converged.item()):
+                    break
+            for _ in range(second_order_iters):
+                self.step_second_order()
                 it += 1
-            if int(self.converged.item()):
-                break
-        if not self.check_capacity():
-            raise RuntimeError("pair capacity exceeded during tracking; re-run with the grown workspace")
-        return it
+            if self.check_capacity():
+                return it
+            self._restore(keep)
+        raise RuntimeError("pair capacity still exceeded after growing the workspaces three times")
