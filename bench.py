@@ -456,17 +456,11 @@ def main(argv=None):
         tracking = bench_tracking(sc, dev, args.tracking_iters)
         map_update = bench_map_update(sc, dev)
     if single and not args.no_mapping:
-        try:
-            from monogs_amd.bench_legs import bench_mapping
-            mapping = bench_mapping(sc, dev)
-        except ImportError:
-            mapping = None
+        from monogs_amd.bench_legs import bench_mapping
+        mapping = bench_mapping(sc, dev)
     if single and not args.no_slam:
-        try:
-            from monogs_amd.bench_legs import bench_slam_surrogate
-            slam = bench_slam_surrogate(dev)
-        except ImportError:
-            slam = None
+        from monogs_amd.bench_legs import bench_slam_surrogate
+        slam = bench_slam_surrogate(dev)
 
     if rank == 0:
         out = {

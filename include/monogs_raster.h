@@ -95,15 +95,22 @@ typedef struct mgs_forward_args {
   float* out_opacity;  /* [1,H,W] */
   int32_t* radii;      /* [N] */
   int32_t* n_touched;  /* [N] */
-  /* optional: stage 1 also stores the pair count D here.  May be pinned HOST memory
-   * (device-accessible): the caller then learns D from an event recorded after stage 1
-   * without a device-to-host copy in the stream. */
+  /* optional, TWO ints: stage 1 also stores [0] = the pair count D and [1] = the largest number of
+   * pairs in one tile here.  May be pinned HOST memory (device-accessible): the caller then learns
+   * both from an event recorded after stage 1 without a device-to-host copy in the stream. */
   int32_t* pair_count_out;
   /* optional DEVICE counter: stage 1 does atomicMax(*pair_count_max, D).  Never reset by the
    * library, so after any number of fixed-capacity forwards (mgs_tracking_iteration,
    * mgs_mapping_view_iteration) *pair_count_max > pair_capacity says that at least one of them
    * was rendered incompletely, whichever it was. */
   int32_t* pair_count_max;
+  /* Stage 2 sorts tiles of up to 1024 pairs in one launch and tiles of 1025..4096 pairs in a second
+   * one (16-wave workgroups, 32 KB of LDS) that costs ~6 us even when no such tile exists.
+   * 0 (default): always launch it.  -1: skip it - a caller that knows from pair_count_out[1] of the
+   * previous, nearly identical view that no tile is that crowded; should one appear after all, the
+   * first launch sorts it in place in HBM (slower, same order). */
+  int32_t big_tile_pass;
+  int32_t reserved0;
 } mgs_forward_args;
 
 /* Mapping mode of the backward (row a13, utils/slam_backend.py:171-332): instead of storing
@@ -167,6 +174,13 @@ typedef struct mgs_backward_args {
    * then be NULL, scales / rotations / opacities / shs of `fwd` must be the outputs of
    * mgs_map_activate, and the gradients are chained and accumulated as described above. */
   const mgs_map_accum_args* map_accum;
+  /* How the backward treats the field-of-view clamp of the EWA Jacobian, t.x = clamp(x/z) * z
+   * (only splats whose centre lies outside 1.3x the field of view are affected; the forward is the
+   * same): 0 = the exact derivative of the forward (default; what the oracle's autograd gives),
+   * 1 = t.x held constant in z and its x-gradient zeroed when clamped - what the public CUDA lineage
+   * of the absent extension is believed to do (DESIGN.md §2 quantifies the difference). */
+  int32_t clamp_gradient_mode;
+  int32_t reserved0;
 } mgs_backward_args;
 
 int32_t mgs_abi_version(void);
@@ -282,6 +296,12 @@ typedef struct mgs_mapping_loss_args {
   float* grad_depth;         /* [1,H,W] or NULL */
   float* grad_a;             /* [1] or NULL */
   float* grad_b;             /* [1] or NULL */
+  /* != 0: the caller guarantees that the int at partial[2 n] (n = partial count / 3) was zero when
+   * the call was enqueued (e.g. a scratch zeroed once and reused: every call restores the zero).
+   * mgs_mapping_loss_forward then sums the block partials in the workgroup that finishes last
+   * instead of launching a second kernel. */
+  int32_t partial_ticket_ready;
+  int32_t reserved0;
 } mgs_mapping_loss_args;
 
 int32_t mgs_mapping_loss_forward(const mgs_mapping_loss_args* args, void* stream);

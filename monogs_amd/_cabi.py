@@ -50,7 +50,7 @@ class ForwardArgs(C.Structure):
         "means3D", "scales", "rotations", "cov3D_precomp", "opacities", "shs", "colors_precomp",
         "viewmatrix", "projmatrix", "projmatrix_raw", "campos", "bg", "geom", "bins",
         "out_color", "out_depth", "out_opacity", "radii", "n_touched", "pair_count_out",
-        "pair_count_max")]
+        "pair_count_max")] + [("big_tile_pass", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class MapAccumArgs(C.Structure):
@@ -67,7 +67,8 @@ class BackwardArgs(C.Structure):
         "grad_opacities", "grad_scales", "grad_rotations", "grad_cov3D", "grad_tau")]
         + [("sketch_mode", C.c_int32), ("sketch_dim", C.c_int32), ("stack_dim", C.c_int32),
            ("sketch_indices", _fp), ("grad_sketch_dtau", _fp), ("sketch_ws", _fp),
-           ("sketch_bucket_flat", _fp), ("map_accum", C.POINTER(MapAccumArgs))])
+           ("sketch_bucket_flat", _fp), ("map_accum", C.POINTER(MapAccumArgs)),
+           ("clamp_gradient_mode", C.c_int32), ("reserved0", C.c_int32)])
 
 
 class PoseAdamArgs(C.Structure):
@@ -89,7 +90,8 @@ class MappingLossArgs(C.Structure):
                    ("depth_mask_threshold", C.c_float), ("apply_exposure", C.c_int32),
                    ("num_pixels", C.c_int64)]
                 + [(n, _fp) for n in ("partial", "loss", "grad_out", "grad_image", "grad_depth",
-                                      "grad_a", "grad_b")])
+                                      "grad_a", "grad_b")]
+                + [("partial_ticket_ready", C.c_int32), ("reserved0", C.c_int32)])
 
 
 class LMStepArgs(C.Structure):

@@ -26,6 +26,7 @@ __device__ __forceinline__ void load_camera_b(Camera& c, const KP& P) {
   c.W = P.W; c.H = P.H; c.tanfovx = P.tanfovx; c.tanfovy = P.tanfovy;
   c.focal_x = P.focal_x; c.focal_y = P.focal_y; c.scale_modifier = P.mod;
   c.sh_degree = P.deg; c.sh_coeffs = P.K; c.grid_x = P.grid_x; c.grid_y = P.grid_y;
+  c.clamp_grad_upstream = P.clamp_up;
 }
 
 // ---------------------------------------------------------------------------------
@@ -506,12 +507,25 @@ __global__ __launch_bounds__(kPreBlock) void k_preprocess_bwd(KP P, KB B) {
       float a[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       // clamped to the capacity of the pair_grad buffer (see k_blend_bwd)
       const int s0 = min(pair_slot_base(P, idx), P.cap), s1 = min(s0 + P.pair_count[idx], P.cap);
-      for (int s = s0; s < s1; s++) {
-        const float4* src = B.pair_grad + (size_t)s * 3;
-        const float4 x = src[0], y = src[1], z = src[2];
-        a[0] += x.x; a[1] += x.y; a[2] += x.z; a[3] += x.w;
-        a[4] += y.x; a[5] += y.y; a[6] += y.z; a[7] += y.w;
-        a[8] += z.x; a[9] += z.y;
+      // four slots in flight per trip (predicated loads, issued back to back): the loop is bound by
+      // load latency, not by bytes - one slot per trip costs one round trip per pair of the Gaussian
+      for (int s = s0; s < s1; s += 4) {
+        float4 x[4], y[4], z[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+          x[u] = y[u] = z[u] = zero;
+          if (s + u < s1) {
+            const float4* src = B.pair_grad + (size_t)(s + u) * 3;
+            x[u] = src[0]; y[u] = src[1]; z[u] = src[2];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {     // same summation order as one slot per trip
+          a[0] += x[u].x; a[1] += x[u].y; a[2] += x[u].z; a[3] += x[u].w;
+          a[4] += y[u].x; a[5] += y[u].y; a[6] += y[u].z; a[7] += y[u].w;
+          a[8] += z[u].x; a[9] += z[u].y;
+        }
       }
       if (!MAP && !B.g_means3D) { a[0] = 0.f; a[6] = 0.f; a[7] = 0.f; a[8] = 0.f; }   // pose-only: not produced
       // a[] = raw pixel sums (S1, Sx, Sy, Sxx, Sxy, Syy, Rr, Rg, Rb, Rd) over all tiles of
@@ -666,13 +680,21 @@ __global__ void k_visibility_only(const int* n_touched, unsigned char* vis, int 
 // Fixed-order sum of the block partials -> grad_tau[6].  (Folding this into k_preprocess_bwd
 // with a last-workgroup ticket was measured slower: the hand-off makes every workgroup drain
 // its 20 MB of gradient stores before it may retire.)
-__global__ __launch_bounds__(384) void k_tau_reduce(KB B, int nblk) {
-  // 6 components x 64 lanes; each lane strides the partials, then a wave sum.
-  const int comp = threadIdx.x >> 6, lane = threadIdx.x & 63;
+__global__ __launch_bounds__(768) void k_tau_reduce(KB B, int nblk) {
+  // 6 components x 2 halves of the partials x 64 lanes; every lane's loads are independent (fully
+  // unrolled in flight), then a wave sum, then the two halves are added in a fixed order.
+  __shared__ float s_half[12];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int comp = wave % 6, half = wave / 6;
+  const int mid = (nblk + 1) / 2;
+  const int i0 = half ? mid : 0, i1 = half ? nblk : mid;
   float s = 0.f;
-  for (int i = lane; i < nblk; i += 64) s += B.tau_partial[i * 6 + comp];
+#pragma unroll 16
+  for (int i = i0 + lane; i < i1; i += 64) s += B.tau_partial[i * 6 + comp];
   s = wave_sum_to_lane63(s);
-  if (lane == 63) B.g_tau[comp] = s;
+  if (lane == 63) s_half[wave] = s;
+  __syncthreads();
+  if (threadIdx.x < 6) B.g_tau[threadIdx.x] = s_half[threadIdx.x] + s_half[6 + threadIdx.x];
 }
 
 int launch_visibility(const int* n_touched, unsigned char* vis, int n, hipStream_t st) {
@@ -705,7 +727,7 @@ int launch_backward(const KP& P, const KB& B, hipStream_t st, bool skip_tau_redu
   const int npre = (P.N + kPreBlock - 1) / kPreBlock;
   if (B.map.on) launch("preprocess_bwd_map", k_preprocess_bwd<true>, dim3(npre), dim3(kPreBlock), st, P, B);
   else launch("preprocess_bwd", k_preprocess_bwd<false>, dim3(npre), dim3(kPreBlock), st, P, B);
-  if (!skip_tau_reduce) launch("tau_reduce", k_tau_reduce, dim3(1), dim3(384), st, B, npre);
+  if (!skip_tau_reduce) launch("tau_reduce", k_tau_reduce, dim3(1), dim3(768), st, B, npre);
   return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
 }
 

@@ -90,6 +90,8 @@ int fill_kp(const mgs_forward_args& a, bool need_bins, bool need_outputs, KP& P)
   P.max_segs = (int)L.max_segs;
   P.out_color = a.out_color; P.out_depth = a.out_depth; P.out_opacity = a.out_opacity;
   P.radii = a.radii; P.n_touched = a.n_touched; P.d_out = a.pair_count_out; P.d_max = a.pair_count_max;
+  P.big_pass = a.big_tile_pass < 0 ? 0 : 1;
+  P.clamp_up = 0;
   return MGS_OK;
 }
 
@@ -172,6 +174,8 @@ static int32_t raster_backward_impl(const mgs_backward_args* args, void* stream,
   const int rc = fill_kp(args->fwd, true, false, P);
   if (rc != MGS_OK) return rc;
   if (!args->grad_color || !args->bwd || !args->grad_tau) return MGS_ERR_BAD_ARGUMENT;
+  if (args->clamp_gradient_mode != 0 && args->clamp_gradient_mode != 1) return MGS_ERR_BAD_ARGUMENT;
+  P.clamp_up = args->clamp_gradient_mode;
   {   // per-Gaussian gradients: all of the mandatory four, or none at all (pose-only / mapping mode)
     const int have = (args->grad_means3D != nullptr) + (args->grad_means2D != nullptr) +
                      (args->grad_colors != nullptr) + (args->grad_opacities != nullptr);

@@ -30,14 +30,13 @@ __device__ __forceinline__ void load_camera(Camera& c, const KP& P) {
   c.W = P.W; c.H = P.H; c.tanfovx = P.tanfovx; c.tanfovy = P.tanfovy;
   c.focal_x = P.focal_x; c.focal_y = P.focal_y; c.scale_modifier = P.mod;
   c.sh_degree = P.deg; c.sh_coeffs = P.K; c.grid_x = P.grid_x; c.grid_y = P.grid_y;
+  c.clamp_grad_upstream = P.clamp_up;
 }
 
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(kPreBlock) void k_preprocess(KP P) {
-  const int idx = blockIdx.x * kPreBlock + threadIdx.x;
-  for (int i = idx; i < P.T; i += gridDim.x * kPreBlock) P.tile_count[i] = 0;
-  if (idx < 4) P.counters[idx] = 0;
-  if (idx >= P.N) return;
+// Projection + EWA of Gaussian idx -> its 48-B record (stored) and radius; returns the two
+// record quads the binning needs.
+__device__ __forceinline__ void project_and_store(const KP& P, int idx, float4& r0, float4& r1) {
   Camera cam;
   load_camera(cam, P);
   const float p[3] = {P.means[3 * idx], P.means[3 * idx + 1], P.means[3 * idx + 2]};
@@ -57,12 +56,24 @@ __global__ __launch_bounds__(kPreBlock) void k_preprocess(KP P) {
     const float q[4] = {qq.x, qq.y, qq.z, qq.w};
     project_gaussian(cam, p, sc, q, nullptr, psh, pcol, P.opac[idx], rec);
   }
+  r0 = make_float4(rec.x, rec.y, rec.depth, rec.opacity);
+  r1 = make_float4(rec.ca, rec.cb, rec.cc, __int_as_float(rec.radius));
   float4* dst = reinterpret_cast<float4*>(P.rec + idx);
-  dst[0] = make_float4(rec.x, rec.y, rec.depth, rec.opacity);
-  dst[1] = make_float4(rec.ca, rec.cb, rec.cc, __int_as_float(rec.radius));
+  dst[0] = r0;
+  dst[1] = r1;
   dst[2] = make_float4(rec.r, rec.g, rec.b, __uint_as_float(rec.flags));
   P.radii[idx] = rec.radius;
 }
+
+__global__ __launch_bounds__(kPreBlock) void k_preprocess(KP P) {
+  const int idx = blockIdx.x * kPreBlock + threadIdx.x;
+  for (int i = idx; i < P.T; i += gridDim.x * kPreBlock) P.tile_count[i] = 0;
+  if (idx < 4) P.counters[idx] = 0;
+  if (idx >= P.N) return;
+  float4 r0, r1;
+  project_and_store(P, idx, r0, r1);
+}
+
 
 // ---------------------------------------------------------------------------------
 // Binning.  Count (emit = 0) or emit (emit = 1) the (tile, Gaussian) pairs.  The culling
@@ -95,13 +106,16 @@ __device__ __forceinline__ void bin_one_pair(const KP& P, int* s_tile, int emit,
   }
 }
 
-__global__ __launch_bounds__(kBinThreads) void k_bin_lds(KP P, int emit, int per_block) {
+// project != 0 (count pass only): the projection itself runs here too - the count pass is the
+// first consumer of the records, so k_preprocess's launch and the re-read of its output go away.
+__global__ __launch_bounds__(kBinThreads) void k_bin_lds(KP P, int emit, int per_block, int project) {
   extern __shared__ int s_tile[];
   __shared__ int s_wave[kBinThreads / 64];
   int carry = 0;
   const int tid = threadIdx.x, lane = tid & 63;
   int* row = P.bin_table + (size_t)blockIdx.x * P.T;
   for (int t = tid; t < P.T; t += kBinThreads) s_tile[t] = emit ? (P.tile_offset[t] + row[t]) : 0;
+  if (project && blockIdx.x == 0 && tid < 4) P.counters[tid] = 0;   // consumed by later launches only
   if (emit)   // the blend pass accumulates n_touched; every (re)run of stage 2 starts from zero
     for (int i = blockIdx.x * kBinThreads + tid; i < P.N; i += gridDim.x * kBinThreads) P.n_touched[i] = 0;
   __syncthreads();
@@ -111,8 +125,12 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_lds(KP P, int emit, int per
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
     int radius = 0;
     if (idx < g1) {
-      r0 = reinterpret_cast<const float4*>(P.rec + idx)[0];
-      r1 = reinterpret_cast<const float4*>(P.rec + idx)[1];
+      if (project) {
+        project_and_store(P, idx, r0, r1);
+      } else {
+        r0 = reinterpret_cast<const float4*>(P.rec + idx)[0];
+        r1 = reinterpret_cast<const float4*>(P.rec + idx)[1];
+      }
       radius = __float_as_int(r1.w);
     }
     int cnt = 0;
@@ -300,7 +318,10 @@ __global__ __launch_bounds__(256) void k_scan_write(KP P) {
 // Exclusive scans of the T tile counts (-> tile_offset, D) and of the per-tile segment
 // backward item counts ceil(n_t / kItem) (-> seg_offset) by one 1024-thread workgroup.
 __device__ __forceinline__ void tile_scan_body(const KP& P, int nbin, int* s_sum, int* s_seg) {
+  __shared__ int s_tmax;
   const int tid = threadIdx.x;
+  if (tid == 0) s_tmax = 0;
+  __syncthreads();
   if (nbin > 0) {   // exclusive scan of the binning blocks' pair totals (nbin <= 1024)
     const int v = tid < nbin ? P.scan_tmp[tid] : 0;
     s_sum[tid] = v;
@@ -319,11 +340,17 @@ __device__ __forceinline__ void tile_scan_body(const KP& P, int nbin, int* s_sum
   }
   const int per = (P.T + 1023) / 1024;
   const int lo = tid * per, hi = min(lo + per, P.T);
-  int local = 0, lseg = 0;
+  int local = 0, lseg = 0, lmax = 0;
   for (int i = lo; i < hi; i++) {
     const int c = __hip_atomic_load(&P.tile_count[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     local += c;
     lseg += (c + kItem - 1) / kItem;
+    lmax = max(lmax, c);
+  }
+  if (P.d_out) {   // largest tile, for the caller's choice of sort launches
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lmax = max(lmax, __shfl_xor(lmax, off));
+    if ((tid & 63) == 0 && lmax > 0) atomicMax(&s_tmax, lmax);   // LDS; read behind the scan's barriers
   }
   s_sum[tid] = local;
   s_seg[tid] = lseg;
@@ -348,8 +375,11 @@ __device__ __forceinline__ void tile_scan_body(const KP& P, int nbin, int* s_sum
     P.tile_offset[P.T] = s_sum[1023];
     P.seg_offset[P.T] = s_seg[1023];
     P.counters[0] = s_sum[1023];
+    if (P.d_out) {   // all waves passed the barriers of the scan above: the maximum is complete
+      __hip_atomic_store(P.d_out + 1, s_tmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(P.d_out, s_sum[1023], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     P.counters[1] = s_seg[1023];
-    if (P.d_out) __hip_atomic_store(P.d_out, s_sum[1023], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (P.d_max) atomicMax(P.d_max, s_sum[1023]);
   }
 }
@@ -563,7 +593,7 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(KP P) {
       if (s0 + i < P.max_segs)
         P.seg_rec[s0 + i] = make_int4(tile, min(start + i * kItem, P.cap), max(0, min(kItem, n - i * kItem)), i * kItem);
   }
-  if (n <= 1 || n <= MIN_N || (MIN_N == 0 && n > CAP)) continue;   // workgroup-uniform
+  if (n <= 1 || n <= MIN_N || (MIN_N == 0 && n > CAP && P.big_pass)) continue;   // workgroup-uniform
   unsigned long long* gk = P.keys + start;
   unsigned int* gv = PACKED ? nullptr : P.payload + start;
   if (n <= CAP) {
@@ -683,15 +713,23 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
     const float4 na = src1[0], nb4 = src1[1], nc = src1[2];
     id_n1 = fwd_load_id(P, start, n, base + 2 * kSeg + lane);
 
+#if defined(MGS_ABL) && MGS_ABL == 7
+    if (false) {
+#else
     if (base > 0 && base % kItem == 0) {   // checkpoint: state in front of this backward item
+#endif
       const int sg = seg0 + base / kItem;
       if (sg < P.max_segs) {
         float* ck = P.ckpt + (size_t)sg * (5 * 256) + ptile;
         ck[0] = T; ck[256] = C01.x; ck[512] = C01.y; ck[768] = C2D.x; ck[1024] = C2D.y;
       }
     }
+#if defined(MGS_ABL) && MGS_ABL == 8
+    const bool reach = base + lane < n && fabsf(ca.x - bx0 - 3.5f) < 12.f && fabsf(ca.y - by0 - 3.5f) < 12.f;
+#else
     const bool reach = base + lane < n &&
                        box_reachable(ca.x, ca.y, cb.x, cb.y, cb.z, splat_qmax(ca.w), bx0, by0, bx1, by1);
+#endif
     unsigned long long m = __builtin_amdgcn_ballot_w64(reach);
     int touched = 0;
     if (m != 0ull) {
@@ -761,7 +799,9 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
       if (count_touch) walk(std::true_type{});
       else walk(std::false_type{});
     }
+#if !(defined(MGS_ABL) && MGS_ABL == 6)
     if (touched > 0) atomicAdd(&P.n_touched[cid], touched);
+#endif
     if (__builtin_amdgcn_ballot_w64(live != 0.f) == 0ull) break;   // quadrant saturated
     cid = nid; ca = na; cb = nb4; cc = nc;
   }
@@ -813,13 +853,12 @@ static inline int bin_blocks(int N) {
 }
 
 int launch_forward_project(const KP& P, hipStream_t st) {
-  const int nblk = (P.N + kPreBlock - 1) / kPreBlock;
-  launch("preprocess", k_preprocess, dim3(nblk), dim3(kPreBlock), st, P);
   if (P.T <= kBinMaxTilesLds) {
     const int nblk = bin_blocks(P.N), per = (P.N + nblk - 1) / nblk;
-    launch_smem("bin_count", k_bin_lds, dim3(nblk), dim3(kBinThreads), sizeof(int) * (size_t)P.T, st, P, 0, per);
+    launch_smem("project_bin_count", k_bin_lds, dim3(nblk), dim3(kBinThreads), sizeof(int) * (size_t)P.T, st, P, 0, per, 1);
     launch("bin_colsum", k_bin_colsum, dim3((P.T + 63) / 64), dim3(64 * kColGroups), st, P, nblk);   // + tile scan
   } else {
+    launch("preprocess", k_preprocess, dim3((P.N + kPreBlock - 1) / kPreBlock), dim3(kPreBlock), st, P);
     launch("bin_count", k_bin, dim3((P.N + 255) / 256), dim3(256), st, P, 0);
     const int nscan = (P.N + kScanBlock - 1) / kScanBlock;
     launch("scan_reduce", k_scan_reduce, dim3(nscan), dim3(256), st, P);
@@ -835,7 +874,7 @@ int launch_forward_blend(const KP& P, hipStream_t st) {
   // (n_touched is zeroed by the emit pass of the LDS path)
   if (P.T <= kBinMaxTilesLds) {
     const int nblk = bin_blocks(P.N), per = (P.N + nblk - 1) / nblk;
-    launch_smem("bin_emit", k_bin_lds, dim3(nblk), dim3(kBinThreads), sizeof(int) * (size_t)P.T, st, P, 1, per);
+    launch_smem("bin_emit", k_bin_lds, dim3(nblk), dim3(kBinThreads), sizeof(int) * (size_t)P.T, st, P, 1, per, 0);
   } else {
     if (hipMemsetAsync(P.tile_cursor, 0, sizeof(int) * (size_t)P.T, st) != hipSuccess ||
         hipMemsetAsync(P.n_touched, 0, sizeof(int) * (size_t)P.N, st) != hipSuccess)
@@ -847,10 +886,10 @@ int launch_forward_blend(const KP& P, hipStream_t st) {
   // tile of a 320x240 view holds ~2500 splats)
   if (P.pack) {
     launch("tile_sort", k_tile_sort<1024, 0, true, 256>, dim3(P.T), dim3(256), st, P);
-    launch("tile_sort_big", k_tile_sort<4096, 1024, true, 1024>, dim3(min(P.T, 512)), dim3(1024), st, P);
+    if (P.big_pass) launch("tile_sort_big", k_tile_sort<4096, 1024, true, 1024>, dim3(min(P.T, 512)), dim3(1024), st, P);
   } else {
     launch("tile_sort", k_tile_sort<1024, 0, false, 256>, dim3(P.T), dim3(256), st, P);
-    launch("tile_sort_big", k_tile_sort<4096, 1024, false, 1024>, dim3(min(P.T, 512)), dim3(1024), st, P);
+    if (P.big_pass) launch("tile_sort_big", k_tile_sort<4096, 1024, false, 1024>, dim3(min(P.T, 512)), dim3(1024), st, P);
   }
   launch("blend_fwd", k_blend_fwd, dim3(grid_pad(4 * P.T, kFwdChunk)), dim3(64), st, P);
   return check_launch();

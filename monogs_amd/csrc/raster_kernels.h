@@ -48,6 +48,8 @@ struct KP {
   int *radii, *n_touched;
   int* d_out;              // optional extra destination of D (may be pinned host memory)
   int* d_max;              // optional sticky high-water mark of D (atomicMax)
+  int big_pass;            // 1: tiles of more than 1024 pairs are left to the second sort launch
+  int clamp_up;            // backward: mgs_backward_args.clamp_gradient_mode
 };
 
 struct KM {   // mapping mode of the preprocess backward (mgs_map_accum_args)

@@ -63,6 +63,7 @@ struct Camera {
   int sh_degree;   // active degree
   int sh_coeffs;   // K = number of coefficient triples stored per Gaussian
   int grid_x, grid_y;
+  int clamp_grad_upstream;   // backward only: 0 = exact derivative of the EWA clamp, 1 = t.x constant in z
 };
 
 MGS_HD float clampf(float v, float lo, float hi) { return fminf(hi, fmaxf(lo, v)); }
@@ -434,8 +435,11 @@ MGS_HD void project_gaussian_backward(const Camera& cam, const float p[3], const
   const float g_tyc = dJ[5] * (-fy * itz2);
   float g_tz = dJ[0] * (-fx * itz2) + dJ[4] * (-fy * itz2) + dJ[2] * (2.f * fx * cv.txc * itz3) +
                dJ[5] * (2.f * fy * cv.tyc * itz3);
-  if (cv.clamp_x) g_tz += g_txc * cv.txc * itz; else gpc[0] += g_txc;
-  if (cv.clamp_y) g_tz += g_tyc * cv.tyc * itz; else gpc[1] += g_tyc;
+  // t.x = clamp(x/z) z: unclamped it equals x (no z dependence); clamped it is c z, whose exact
+  // derivative feeds z.  The public CUDA lineage is believed to multiply the x-gradient by 0 when
+  // clamped and to keep t.x constant in z (mode 1); the forward is the same.
+  if (cv.clamp_x) { if (!cam.clamp_grad_upstream) g_tz += g_txc * cv.txc * itz; } else gpc[0] += g_txc;
+  if (cv.clamp_y) { if (!cam.clamp_grad_upstream) g_tz += g_tyc * cv.tyc * itz; } else gpc[1] += g_tyc;
   gpc[2] += g_tz;
   // ---- mean and pose ---------------------------------------------------------------
   // p_c = Rv p + tv:  dL/dp = Rv^T gpc ;  Rv^T[i][k] = Rv[k][i] = V[4i+k]

@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void k_lm_solve_step(mgs_lm_step_args A) {
 // with m = rgb_pixel_mask_mapping and dm = gt_depth > 0.01 (RGB-D only; w_depth = 0 for
 // monocular).  apply_exposure = 0 reproduces `initialization=True` (image used as is).
 // One streaming pass for the value, one for the gradients.
-__global__ __launch_bounds__(kLossBlock) void k_map_loss_fwd(mgs_mapping_loss_args A) {
+__global__ __launch_bounds__(kLossBlock) void k_map_loss_fwd(mgs_mapping_loss_args A, int fused_finish) {
   __shared__ float s_red[kLossBlock / 64];
   const float gain = A.apply_exposure ? fabsf(A.exposure_a[0]) + A.exposure_eps : 1.f;
   const float bias = A.apply_exposure ? A.exposure_b[0] : 0.f;
@@ -371,7 +371,39 @@ __global__ __launch_bounds__(kLossBlock) void k_map_loss_fwd(mgs_mapping_loss_ar
   }
   const float tc = block_sum(sc, s_red);
   const float td = block_sum(sd, s_red);
-  if (threadIdx.x == 0) { A.partial[blockIdx.x] = tc; A.partial[gridDim.x + blockIdx.x] = td; }
+  if (threadIdx.x == 0) {   // write-through (sc1) stores: visible to the last workgroup's sc1 loads without a fence
+    __hip_atomic_store(&A.partial[blockIdx.x], tc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&A.partial[gridDim.x + blockIdx.x], td, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (!fused_finish) return;
+  // The workgroup that finishes last sums the block partials (saves the dependent finish launch).
+  // Fence-free hand-off as in k_bin_colsum (MI355X_MICROARCH.md, "Hand-offs measured with sc1
+  // loads"): the two partials were stored write-through, the storing lane drains them
+  // (s_waitcnt) and takes an agent-scope ticket; the last arriver reads with sc1 loads.  A full
+  // __threadfence() here costs an L2 write-back per workgroup: 7.7 -> 17 us for this kernel.
+  // The ticket (the int behind the 2 n partials) is zero on entry and is reset here, so the same
+  // scratch serves the next call.
+  __shared__ int s_last;
+  if (threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int* ticket = reinterpret_cast<int*>(A.partial + 2 * gridDim.x);
+    s_last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+    if (s_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  const int nblk = gridDim.x;
+  float x = 0.f, y = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += kLossBlock) {
+    x += __hip_atomic_load(&A.partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    y += __hip_atomic_load(&A.partial[nblk + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const float sumc = block_sum(x, s_red);
+  const float sumd = block_sum(y, s_red);
+  if (threadIdx.x == 0) {
+    const float hw = (float)A.num_pixels;
+    A.loss[0] = A.w_rgb * sumc / (3.f * hw) + A.w_depth * sumd / hw;
+  }
 }
 
 __global__ __launch_bounds__(kLossBlock) void k_map_loss_finish(mgs_mapping_loss_args A, int nblk) {
@@ -612,8 +644,9 @@ static bool map_args_ok(const mgs_mapping_loss_args* a) {
 int32_t mgs_mapping_loss_forward(const mgs_mapping_loss_args* a, void* stream) {
   if (!map_args_ok(a)) return MGS_ERR_BAD_ARGUMENT;
   const int nb = loss_blocks(a->num_pixels);
-  launch("map_loss_fwd", k_map_loss_fwd, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a);
-  launch("map_loss_finish", k_map_loss_finish, dim3(1), dim3(kLossBlock), (hipStream_t)stream, *a, nb);
+  launch("map_loss_fwd", k_map_loss_fwd, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a, a->partial_ticket_ready ? 1 : 0);
+  if (!a->partial_ticket_ready)
+    launch("map_loss_finish", k_map_loss_finish, dim3(1), dim3(kLossBlock), (hipStream_t)stream, *a, nb);
   return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
 }
 

@@ -113,7 +113,7 @@ class NativeMapper:
         self.capacity = 0
         self._N = -1
         self._shape_key = None
-        self._host_D = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._host_D = torch.zeros(2, dtype=torch.int32).pin_memory()      # [0] = D, [1] = fullest tile
         self._d_max = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.loss_accum = torch.zeros(1, device=self.dev)
         self.last_loss = None
@@ -226,6 +226,7 @@ class NativeMapper:
         f.out_color, f.out_depth, f.out_opacity = self.color.data_ptr(), self.depth.data_ptr(), self.opacity.data_ptr()
         f.radii, f.n_touched = self.radii.data_ptr(), self.n_touched.data_ptr()
         f.pair_count_out, f.pair_count_max = self._host_D.data_ptr(), self._d_max.data_ptr()
+        f.big_tile_pass = -1 if 0 < int(self._host_D[1]) <= 900 else 0
         a.bwd, a.grad_image, a.grad_tau = self.bwd.data_ptr(), self.grad_image.data_ptr(), self.grad_tau.data_ptr()
         a.grad_depth = self.grad_depth.data_ptr()
         # objective (utils/slam_utils.py:224-253)
@@ -299,7 +300,7 @@ class NativeMapper:
                                              st.full.data_ptr(), self._stream()), "mgs_camera_from_pose")
         _cabi.check(lib.mgs_raster_forward_project(C.byref(a.fwd), self._stream()), "mgs_raster_forward_project")
         torch.cuda.current_stream(self.dev).synchronize()
-        D = int(self._host_D.item())
+        D = int(self._host_D[0].item())
         self._d_max.zero_()
         self.capacity = max(self.capacity, 1024, (int(D * self.capacity_margin) + 1023) // 1024 * 1024)
         self._need_probe = False
@@ -308,7 +309,7 @@ class NativeMapper:
         if self._need_probe:
             self._probe_capacity(kf_idx)
         # D of an earlier view lands in pinned host memory without a sync: grow BEFORE it overflows
-        seen = int(self._host_D.item())
+        seen = int(self._host_D[0].item())
         if seen > 0.9 * self.capacity:
             self.capacity = (int(seen * self.capacity_margin) + 1023) // 1024 * 1024
             self.overflow_regrows += 1

@@ -37,7 +37,20 @@ class GaussianRasterizationSettings(NamedTuple):
 
 # pair-capacity high-water mark per device: the blend stage is launched optimistically
 # with this capacity while the host waits (concurrently) for the true pair count.
+# Backward treatment of the EWA field-of-view clamp (include/monogs_raster.h: clamp_gradient_mode):
+# "exact" (default) or "upstream" (stop-gradient through the clamp, as the absent CUDA extension is
+# believed to behave).  Only splats centred outside 1.3x the field of view are affected.
+CLAMP_GRADIENT_MODES = {"exact": 0, "upstream": 1}
+_clamp_gradient_mode = 0
+
+
+def set_clamp_gradient_mode(mode: str) -> None:
+    global _clamp_gradient_mode
+    _clamp_gradient_mode = CLAMP_GRADIENT_MODES[mode]
+
+
 _capacity_hint: dict = {}
+_tile_max_hint: dict = {}
 _bwd_scratch: dict = {}
 last_stats: dict = {}
 
@@ -85,11 +98,11 @@ def _host_counter(dev_index):
     ring = _host_slots.get(dev_index)
     if ring is None:
         ring = _host_slots[dev_index] = {
-            "buf": torch.empty(8, dtype=torch.int32, pin_memory=True),
+            "buf": torch.zeros(16, dtype=torch.int32, pin_memory=True),
             "ev": [torch.cuda.Event() for _ in range(8)], "i": 0}
     i = ring["i"]
     ring["i"] = (i + 1) % 8
-    return ring["buf"][i:i + 1], ring["ev"][i]
+    return ring["buf"][2 * i:2 * i + 2], ring["ev"][i]      # [0] = D, [1] = pairs in the fullest tile
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -146,6 +159,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         # the pair count D lands directly in a pinned host slot (no copy kernel in the stream)
         host_cnt, ev = _host_counter(dev.index)
         a.pair_count_out = host_cnt.data_ptr()
+        # the second sort launch (tiles of 1025..4096 pairs) is skipped while the previous forward on
+        # this device had no tile near that size (a surprise is still sorted correctly, in HBM)
+        a.big_tile_pass = -1 if _tile_max_hint.get(dev.index, 1 << 30) <= 900 else 0
         _cabi.check(lib.mgs_raster_forward_project(C.byref(a), stream), "mgs_raster_forward_project")
         ev.record(torch.cuda.current_stream(dev))
 
@@ -170,7 +186,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                     saved_small + (bins,), st, (N, W, H, int(st.sh_degree), K, int(hint)),
                     (int(sketch_mode), int(sketch_dim), int(stack_dim)))
         ev.synchronize()
-        D = int(host_cnt.item())
+        D = int(host_cnt[0].item())
+        _tile_max_hint[dev.index] = int(host_cnt[1].item())
         if bins is None or D > shape.pair_capacity:
             retried = bins is not None
             prepared = None                  # sized for the old capacity
@@ -247,6 +264,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         b.grad_colors, b.grad_opacities = _ptr(out["g_colors"]), _ptr(out["g_op"])
         b.grad_scales, b.grad_rotations, b.grad_cov3D = _ptr(out["g_sc"]), _ptr(out["g_rot"]), _ptr(out["g_cov"])
         b.grad_tau = _ptr(out["g_tau"])
+        b.clamp_gradient_mode = _clamp_gradient_mode
         out["args"] = b
         return out
 

@@ -68,7 +68,8 @@ def trajectory(n_frames: int, step=(0.012, -0.006, 0.008, 0.004, -0.003, 0.002))
     return [SE3_exp(k * tau) for k in range(n_frames)]
 
 
-def load_sequence(n_frames: int, W: int = 640, H: int = 480, dev="cuda", world_gaussians: int = 150_000, seed: int = 0):
+def load_sequence(n_frames: int, W: int = 640, H: int = 480, dev="cuda", world_gaussians: int = 150_000, seed: int = 0,
+                  sigma_px: float = 2.5):
     """(frames, camera, source): the mounted TUM sequence if MONOGS_TUM_DIR is set, else frames
     rendered from a synthetic world along `trajectory`."""
     cam = S.make_camera(W, H)
@@ -83,7 +84,7 @@ def load_sequence(n_frames: int, W: int = 640, H: int = 480, dev="cuda", world_g
         return frames, cam, f"TUM sequence at {tum}"
     from .gaussian_renderer import render
     poses = trajectory(n_frames)
-    world = make_world(world_gaussians, W, H, poses, seed=seed)
+    world = make_world(world_gaussians, W, H, poses, seed=seed, sigma_px=sigma_px)
     world = GaussianParams(*(t.to(dev) for t in (world._xyz.data, world._scaling.data, world._rotation.data,
                                                  world._opacity.data, world._features_dc.data)))
     fovx, fovy = 2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy)

@@ -135,6 +135,22 @@ def lm_solve_step(SJ: torch.Tensor, Sf: torch.Tensor, lambda_: float, viewpoint=
     return x
 
 
+_loss_scratch: dict = {}
+
+
+def _zeroed_partials(dev, count):
+    """Per-(device, stream) scratch for the loss kernels' block partials, zeroed ONCE: the forward's
+    last-workgroup ticket lives behind the partials and every call restores it to zero, so calls
+    enqueued in order on one stream can share the buffer."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, count)
+    buf = _loss_scratch.get(key)
+    if buf is None:
+        if len(_loss_scratch) > 64:
+            _loss_scratch.clear()
+        buf = _loss_scratch[key] = torch.zeros(count, dtype=torch.float32, device=dev)
+    return buf
+
+
 class _MappingLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, image, depth, gt, gt_depth, mask, exposure_a, exposure_b, exposure_eps, w_rgb,
@@ -146,7 +162,7 @@ class _MappingLoss(torch.autograd.Function):
         f = lambda t: None if t is None else t.detach().float().contiguous()
         image_c, depth_c, gt_c, gtd_c, mask_c = f(image), f(depth), f(gt), f(gt_depth), f(mask)
         HW = int(image_c.shape[-1] * image_c.shape[-2])
-        partial = torch.empty(int(lib.mgs_tracking_loss_partial_count(HW)), dtype=torch.float32, device=dev)
+        partial = _zeroed_partials(dev, int(lib.mgs_tracking_loss_partial_count(HW)))
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         a = _cabi.MappingLossArgs()
         ptr = lambda t: None if t is None else t.data_ptr()
@@ -155,6 +171,7 @@ class _MappingLoss(torch.autograd.Function):
         a.exposure_eps, a.w_rgb, a.w_depth = float(exposure_eps), float(w_rgb), float(w_depth)
         a.depth_mask_threshold, a.apply_exposure, a.num_pixels = float(depth_mask_threshold), int(apply_exposure), HW
         a.partial, a.loss = partial.data_ptr(), loss.data_ptr()
+        a.partial_ticket_ready = 1          # one launch: the last workgroup finishes the sum
         _cabi.check(lib.mgs_mapping_loss_forward(C.byref(a), _stream(dev)), "mgs_mapping_loss_forward")
         ctx.save_for_backward(image_c, depth_c, gt_c, gtd_c, mask_c, exposure_a, exposure_b, partial)
         ctx.consts = (float(exposure_eps), float(w_rgb), float(w_depth), float(depth_mask_threshold),

@@ -85,6 +85,8 @@ class NativeTracker:
         # overflow in the middle of a run is seen even when the last iteration fits
         self._d_max = torch.zeros(1, dtype=torch.int32, device=dev)
         f.pair_count_max = self._d_max.data_ptr()
+        self._host_D = torch.zeros(2, dtype=torch.int32).pin_memory()       # [0] = D, [1] = fullest tile
+        f.pair_count_out = self._host_D.data_ptr()
         _cabi.check(lib.mgs_raster_forward_project(C.byref(f), stream), "mgs_raster_forward_project")
         off = int(sizes.off_counters)
         self._counter = self.geom[off:off + 4].view(torch.int32)
@@ -202,6 +204,8 @@ class NativeTracker:
         self._sync_pose_pointer()
         self.t += 1
         self.args.adam.step = self.t
+        # pinned, written by every forward: no sync needed to read the previous iteration's value
+        self.args.fwd.big_tile_pass = -1 if 0 < int(self._host_D[1]) <= 900 else 0
         self.args.camera_matrices_valid = 1 if self._matrices_fresh else 0
         _cabi.check(_cabi.lib().mgs_tracking_iteration(C.byref(self.args), self._stream()),
                     "mgs_tracking_iteration")

@@ -194,8 +194,17 @@ class Projected(NamedTuple):
 
 
 def project(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-            cov3D_precomp, settings: RasterSettings, tau: Optional[torch.Tensor]):
-    """Per-Gaussian projection + EWA splat (contract rows a4)."""
+            cov3D_precomp, settings: RasterSettings, tau: Optional[torch.Tensor],
+            clamp_grad: str = "exact"):
+    """Per-Gaussian projection + EWA splat (contract rows a4).
+
+    clamp_grad selects how the backward treats the field-of-view clamp of the EWA Jacobian,
+    t.x = clamp(x/z, +-1.3 tanfov) * z (the FORWARD is identical either way):
+      "exact"     plain autograd: for a clamped splat t.x = c*z depends on z and not on x;
+      "upstream"  what the public CUDA lineage is believed to do [UPSTREAM-KNOWLEDGE, source absent]:
+                  t.x is treated as a constant of z, and its gradient towards x is multiplied by 0 when
+                  clamped (x_grad_mul) - i.e. d t.x/dx = [not clamped], d t.x/dz = 0.
+    The two differ only for splats whose centre lies outside 1.3x the field of view."""
     K = CONSTANTS
     dt = means3D.dtype
     H, W = int(settings.image_height), int(settings.image_width)
@@ -238,8 +247,16 @@ def project(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
     focal_y = H / (2.0 * settings.tanfovy)
     tz = torch.where(in_front, depth, torch.ones_like(depth))  # keep culled rows finite
     limx, limy = K["fov_clamp"] * settings.tanfovx, K["fov_clamp"] * settings.tanfovy
-    tx = torch.clamp(p_view[:, 0] / tz, -limx, limx) * tz
-    ty = torch.clamp(p_view[:, 1] / tz, -limy, limy) * tz
+    rx, ry = p_view[:, 0] / tz, p_view[:, 1] / tz
+    tx = torch.clamp(rx, -limx, limx) * tz
+    ty = torch.clamp(ry, -limy, limy) * tz
+    if clamp_grad == "upstream":
+        free_x = ((rx >= -limx) & (rx <= limx)).to(dt)
+        free_y = ((ry >= -limy) & (ry <= limy)).to(dt)
+        tx = tx.detach() + (p_view[:, 0] - p_view[:, 0].detach()) * free_x
+        ty = ty.detach() + (p_view[:, 1] - p_view[:, 1].detach()) * free_y
+    elif clamp_grad != "exact":
+        raise ValueError(clamp_grad)
     zero = torch.zeros_like(tz)
     J = torch.stack([
         focal_x / tz, zero, -(focal_x * tx) / (tz * tz),
@@ -370,7 +387,7 @@ def composite(proj: Projected, settings: RasterSettings):
 
 
 def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-              cov3D_precomp, settings: RasterSettings, theta=None, rho=None):
+              cov3D_precomp, settings: RasterSettings, theta=None, rho=None, clamp_grad: str = "exact"):
     """Oracle of `GaussianRasterizer.forward` (gaussian_renderer/__init__.py:151-168).
     Returns (image, radii, depth, opacity, n_touched) plus an `info` dict."""
     tau = None
@@ -379,7 +396,7 @@ def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotation
         tau = torch.cat([rho if rho is not None else z3,
                          theta if theta is not None else z3])
     proj = project(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                   cov3D_precomp, settings, tau)
+                   cov3D_precomp, settings, tau, clamp_grad)
     image, depth, opacity, n_touched, pairs = composite(proj, settings)
     info = dict(proj=proj, pairs=pairs, n_visible=int((proj.radii > 0).sum()))
     return image, proj.radii, depth, opacity, n_touched, info

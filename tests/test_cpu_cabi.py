@@ -32,7 +32,7 @@ def test_struct_layout_matches_header(built):
     """ctypes mirrors must have the C sizes (LP64: 9*4 bytes shape padded to 40)."""
     from monogs_amd import _cabi
     assert C.sizeof(_cabi.RasterShape) == 36
-    assert C.sizeof(_cabi.ForwardArgs) == 40 + 20 * 8
+    assert C.sizeof(_cabi.ForwardArgs) == 40 + 21 * 8 + 8      # 21 pointers + big_tile_pass + reserved
     assert C.sizeof(_cabi.WorkspaceSizes) == 12 * 8
     # every ctypes mirror against the compiler's sizeof (mgs_struct_size)
     lib = _cabi.lib()
