@@ -420,7 +420,35 @@ class NativeMapper:
                 gaussian_split = gaussian_split or reset
             g.update_learning_rate(self.iteration_count)
             self.last_loss = self.loss_accum.clone()
+        self._sync_views(window)
         return gaussian_split
+
+    def _sync_views(self, window):
+        """Keyframe-parallel: a view's pose and exposure are stepped on the rank that owns it; at
+        the end of a map() call the owners publish them (one small all-reduce: non-owners add zeros),
+        so that every rank holds the whole window's cameras whatever the next window's sharding is."""
+        rank, world = self._world()
+        if world == 1:
+            return
+        buf = torch.zeros(len(window), 18, device=self.dev)
+        for i, kf in enumerate(window):
+            if i % world == rank:
+                vp = self.viewpoints[kf]
+                buf[i, :16] = vp.T.reshape(-1)
+                buf[i, 16], buf[i, 17] = vp.exposure_a.detach().reshape(()), vp.exposure_b.detach().reshape(())
+        if dist.get_backend(self.group) == "gloo":
+            tmp = buf.cpu()
+            dist.all_reduce(tmp, group=self.group)
+            buf = tmp.to(self.dev)
+        else:
+            dist.all_reduce(buf, group=self.group)
+        with torch.no_grad():
+            for i, kf in enumerate(window):
+                vp = self.viewpoints[kf]
+                vp.T.copy_(buf[i, :16].view(4, 4))
+                vp.exposure_a.fill_(float(buf[i, 16]))
+                vp.exposure_b.fill_(float(buf[i, 17]))
+                self.states[kf].matrices_fresh = False
 
     def _split_generator(self):
         """densify_and_split's random offsets (gaussian_model.py:608-609) come from a generator

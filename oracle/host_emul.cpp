@@ -220,6 +220,12 @@ void emul_backward(void* h, const float* bg, const float* means3D, const float* 
 }
 
 // number of OpenMP threads the emulation runs on (bench.py reports it as cpu_baseline.cores)
+// exclusive per-tile pair offsets of the last emul_forward (T + 1 entries)
+void emul_tile_offsets(void* h, int32_t* out, int n) {
+  Ctx& c = *(Ctx*)h;
+  for (int i = 0; i < n && i < (int)c.tile_offset.size(); i++) out[i] = c.tile_offset[i];
+}
+
 int emul_num_threads() { return omp_get_max_threads(); }
 
 }  // extern "C"

@@ -111,3 +111,84 @@ def test_bench_gpus_2_starts_two_ranks(built):
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--lean"], env=env2, cwd=ROOT,
                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     assert r2.returncode != 0 and "WORLD_SIZE" in (r2.stderr + r2.stdout)
+
+
+# ---------------------------------------------------------------------------------------------
+# Keyframe-parallel NATIVE mapping (BASELINE config 5's shape, rehearsed on one GPU): the window's
+# views are sharded over 2 ranks, gradients + statistics accumulate on the device straight into the
+# flat buffer that is all-reduced, every rank applies the identical optimiser step, densification
+# (seeded split noise) and prune decision (all-gathered visibility).  Result must equal the
+# single-process NativeMapper on the same window.
+def _native_mapping_run(group_world, dev, iters=4):
+    from monogs_amd.mapping_native import NativeMapper
+    from test_gpu_mapping import _window_fixture
+    _, gm, views = _window_fixture(N=3000, n_views=6, dev=dev, seed=31)
+    gm.unique_kfIDs = (torch.arange(3000, device=dev) % 6).to(torch.int32)
+    cfg = {"Training": {"window_size": 4, "gaussian_update_every": 3, "gaussian_update_offset": 0}}
+    mp_ = NativeMapper(gm, torch.zeros(3, device=dev), config=cfg)
+    for i, v in enumerate(views):
+        mp_.add_keyframe(i, v)
+    window = [5, 4, 3, 2]
+    mp_.set_window(window)
+    mp_.map(window, iters=iters)          # iteration 3 densifies; views 0, 1 are the random extras
+    n_mid = len(gm)
+    mp_.map(window, prune=True)
+    torch.cuda.synchronize()
+    assert mp_.check_capacity()
+    out = {"n_mid": n_mid, "n": len(gm), "xyz": gm._xyz.detach().cpu(), "opacity": gm._opacity.detach().cpu(),
+           "scaling": gm._scaling.detach().cpu(), "ids": gm.unique_kfIDs.cpu(), "n_obs": gm.n_obs.cpu(),
+           "loss": float(mp_.last_loss)}
+    for v in views:
+        out[f"T{v.uid}"] = v.T.detach().cpu()
+        out[f"a{v.uid}"] = float(v.exposure_a)
+    return out
+
+
+def _native_mapping_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = _native_mapping_run(world, dev)
+    ret[rank] = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in out.items()}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_native_mapper_sharded_over_two_ranks_matches_single_process(built):
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    single = _native_mapping_run(1, torch.device("cuda", 0))
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + ((os.getpid() + 377) % 500)
+    mp.spawn(_native_mapping_worker, args=(2, port, ret), nprocs=2, join=True)
+    r0, r1 = ret[0], ret[1]
+    # the replicas stay identical ...
+    for k in ("n_mid", "n"):
+        assert r0[k] == r1[k]
+    for k in ("xyz", "opacity", "scaling", "ids", "n_obs"):
+        assert np.array_equal(r0[k], r1[k]), k
+    # ... and equal to the single-process result: same rows survive, parameters agree up to the
+    # summation order of the views (Adam normalises the gradient: compare the bulk)
+    assert single["n_mid"] == r0["n_mid"] and single["n"] == r0["n"] and single["n_mid"] != 3000
+    assert np.array_equal(single["ids"].numpy(), r0["ids"]) and np.array_equal(single["n_obs"].numpy(), r0["n_obs"])
+    for k, tol in (("xyz", 2e-4), ("opacity", 5e-3), ("scaling", 2e-4)):
+        close = (np.abs(single[k].numpy() - r0[k]) <= tol).mean()
+        assert close > 0.995, (k, close)
+    # every view's pose / exposure is stepped by the rank that owns it and published to the others at
+    # the end of map(): both ranks hold the whole window
+    for uid in range(6):
+        assert np.array_equal(r0[f"T{uid}"], r1[f"T{uid}"]) and r0[f"a{uid}"] == r1[f"a{uid}"], uid
+        assert np.allclose(r0[f"T{uid}"], single[f"T{uid}"].numpy(), atol=5e-5), uid
+        assert abs(r0[f"a{uid}"] - single[f"a{uid}"]) < 2e-4
+        moved = not np.allclose(r0[f"T{uid}"], _pose0(uid))
+        assert moved == (uid in (5, 4, 3))          # window positions 0..2: pose optimised + update_pose
+
+
+def _pose0(uid):
+    from monogs_amd.parallel import view_pose
+    return view_pose(uid).numpy()

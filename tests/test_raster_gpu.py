@@ -1201,3 +1201,48 @@ def test_hip_matches_the_committed_syn_a_vectors(built):
                    ("grad_opacity", L["o"].grad), ("grad_sh", L["sh"].grad)):
         assert rel_err(g, t(key)) <= BWD_REL, key
     assert rel_err(torch.cat([rh.grad, th.grad]), t("grad_tau")) <= 2e-3
+
+
+def test_tile_scan_handoff_never_reads_stale_counts(built):
+    """k_bin_colsum hands the tile totals to the tile scan inside the same launch (last workgroup,
+    fence-free sc1 store / load).  A reordering would show as a scan over stale totals: the pair
+    count D and tile_offset would disagree with the per-Gaussian pair counts the count pass wrote
+    independently.  Many-workgroup shape (1200x680: 3225 tiles = 51 column workgroups), two scenes
+    alternating so that a stale value is a WRONG value, 40 forwards; the last one is also compared
+    tile by tile with the host emulation's exact-culling counts."""
+    from monogs_amd import _cabi, rasterizer as R, synthetic as S
+    from monogs_amd.rasterizer import GaussianRasterizer
+    from oracle.host_emul import HostEmul
+    dev = _dev()
+    W, H = 1200, 680
+    scenes_ = [S.make_scene(40000, W, H, seed=50), S.make_scene(52000, W, H, seed=51)]
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    last = None
+    for it in range(40):
+        sc = scenes_[it % 2]
+        m, s, r, o, sh = [t.to(dev) for t in _inputs(sc)]
+        N = m.shape[0]
+        m.requires_grad_()
+        img, radii, dep, opa, nt = GaussianRasterizer(gpu_settings(sc.cam, sc.bg, dev))(
+            means3D=m, means2D=torch.zeros(N, 3, device=dev), shs=sh, opacities=o, scales=s, rotations=r)
+        geom = img.grad_fn.saved_tensors[12]
+        cap = R.last_stats["capacity"]
+        sz = _cabi.workspace_sizes(_cabi.RasterShape(N, W, H, 0, 1, cap, sc.cam.tanfovx, sc.cam.tanfovy, 1.0))
+        pc = geom[int(sz.off_pair_count):int(sz.off_pair_count) + 4 * N].view(torch.int32)
+        toff = geom[int(sz.off_tile_offset):int(sz.off_tile_offset) + 4 * (T + 1)].view(torch.int32)
+        cnt = geom[int(sz.off_counters):int(sz.off_counters) + 16].view(torch.int32)
+        D = int(pc.sum())
+        assert int(cnt[0]) == D == int(toff[T]) == R.last_stats["pairs"], (it, int(cnt[0]), D, int(toff[T]))
+        assert int(toff[0]) == 0 and bool((toff[1:] >= toff[:-1]).all())
+        last = (sc, toff.cpu().clone(), _inputs(sc))
+    sc, toff, (m, s, r, o, sh) = last
+    em = HostEmul()
+    em.forward(oracle_settings(sc.cam, sc.bg), m, sh, None, o, s, r, None, exact_cull=True)
+    import ctypes as C
+    from oracle import host_emul as HE
+    if hasattr(HE.lib(), "emul_tile_offsets"):
+        want = torch.empty(T + 1, dtype=torch.int32)
+        HE.lib().emul_tile_offsets(em.h, C.cast(want.data_ptr(), C.POINTER(C.c_int32)), C.c_int(T + 1))
+        # the kernels' culling is conservative by a rounding slack: a handful of borderline pairs may differ
+        assert (toff - want).abs().max().item() <= max(4, em.pairs // 2000)
+    assert abs(int(toff[T]) - em.pairs) <= max(2, em.pairs // 1000)
