@@ -17,3 +17,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o run -- $
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$out/fetch" -o run -- $BENCH > "$out/fetch.log" 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$out/write" -o run -- $BENCH > "$out/write.log" 2>&1
 python3 profiles/summarise.py "$out"
+# 4. SQ counters of the blend kernels (VALU / SALU / LDS instruction counts, busy and wait cycles)
+for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM"; do
+  name=$(echo $grp | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --kernel-trace --output-format csv --pmc $grp -d "$out/sq_$name" -o run -- $BENCH > "$out/sq_$name.log" 2>&1 || echo "pmc group failed: $grp"
+done
+python3 profiles/summarise.py "$out" sq

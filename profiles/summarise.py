@@ -36,7 +36,7 @@ for sub, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == ctr:
             agg[short(r["Kernel_Name"])][ctr].append(float(r["Counter_Value"]))
-traffic = {}
+traffic, raw = {}, {}
 with open(f"{out}/pmc_fetch_write_per_kernel.txt", "w") as fh:
     fh.write("kernel launches FETCH_SIZE_KB WRITE_SIZE_KB traffic_MB=(2*FETCH+WRITE)*1024 uncorrected_MB\n")
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1].get("FETCH_SIZE", [0]))):
@@ -45,14 +45,48 @@ with open(f"{out}/pmc_fetch_write_per_kernel.txt", "w") as fh:
         fe = sum(v["FETCH_SIZE"]) / max(1, len(v["FETCH_SIZE"]))
         wr = sum(v["WRITE_SIZE"]) / max(1, len(v["WRITE_SIZE"]))
         traffic[k] = int((2 * fe + wr) * 1024)
+        raw[k] = int((fe + wr) * 1024)
         fh.write(f"{k} {len(v['FETCH_SIZE'])} {fe:.1f} {wr:.1f} {(2 * fe + wr) * 1024 / 1e6:.1f} {(fe + wr) * 1024 / 1e6:.1f}\n")
-names = {"k_blend_bwd<false>": "blend_bwd", "k_blend_fwd": "blend_fwd", "k_preprocess_bwd": "preprocess_bwd",
-         "k_preprocess": "preprocess", "k_tile_sort<1024, 0, true>": "tile_sort", "k_tile_sort<1024, 0, false>": "tile_sort", "k_bin_lds": "bin_emit"}
+def bench_name(k):
+    """kernel symbol (templates stripped by short()) -> the name bench.py's kernels_us uses"""
+    if k.startswith("k_blend_bwd<false, false, false>") or k == "k_blend_bwd<false>":
+        return "blend_bwd"
+    if k.startswith("k_blend_fwd"):
+        return "blend_fwd"
+    if k.startswith("k_preprocess_bwd"):
+        return "preprocess_bwd"
+    if k.startswith("k_tile_sort<1024"):
+        return "tile_sort"
+    if k.startswith("k_bin_lds"):
+        return "bin_lds"          # count (with the projection) and emit launches averaged
+    if k.startswith("k_bin_colsum"):
+        return "bin_colsum"
+    return None
+
+
+names = {k: bench_name(k) for k in traffic if bench_name(k)}
 json.dump({"workload": "SYN-C 300000 @ 640x480",
            "source": "profiles/collect.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
            "correction": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes: gfx950 FETCH_SIZE counts half of wide "
                          "coalesced loads (MI355X_MICROARCH.md, HBM)",
-           "bytes_per_launch": {names[k]: v for k, v in traffic.items() if k in names}},
+           "bytes_per_launch": {names[k]: v for k, v in traffic.items() if k in names},
+           "uncorrected_bytes_per_launch": {names[k]: raw[k] for k in traffic if k in names}},
           open(f"{out}/pmc_traffic.json", "w"), indent=1)
 print(open(f"{out}/kernel_stats.csv").read())
 print(open(f"{out}/pmc_fetch_write_per_kernel.txt").read())
+
+
+# optional: SQ counter passes (profiles/collect.sh step 4) -> per-kernel averages per launch
+if len(sys.argv) > 2 and sys.argv[2] == "sq":
+    sq = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(f"{out}/sq_*/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            sq[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    with open(f"{out}/sq_counters_per_kernel.txt", "w") as fh:
+        for k, v in sorted(sq.items()):
+            if not (k.startswith("k_blend") or k.startswith("k_preprocess_bwd") or k.startswith("k_tile_sort<1024")):
+                continue
+            fh.write(k + "\n")
+            for c, vals in sorted(v.items()):
+                fh.write(f"  {c:28s} {sum(vals) / len(vals):16.0f}  (avg of {len(vals)} launches)\n")
+    print(open(f"{out}/sq_counters_per_kernel.txt").read())
