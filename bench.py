@@ -255,7 +255,7 @@ def main(argv=None):
         entry.build()
     from monogs_amd import _cabi, rasterizer as R, synthetic as S
     from monogs_amd.parallel import FlatGradBucket, view_pose
-    from monogs_amd.tracking_fused import l1_image_depth_loss
+    from monogs_amd.tracking_fused import l1_image_depth_loss_backward
 
     wW, wH, intr, wname = WORKLOADS[args.workload]
     N, W, H = args.gaussians, args.width or wW, args.height or wH
@@ -287,9 +287,9 @@ def main(argv=None):
         img, radii, dep, opa, nt = ras(means3D=params[0], means2D=m2d, shs=params[4],
                                        opacities=params[3], scales=params[1],
                                        rotations=params[2], theta=theta, rho=rho)
-        # L = mean|image - G| + 0.05 mean|depth - Gd|, fused HIP loss kernels
-        loss = l1_image_depth_loss(img, dep, gt_img, gt_dep, 0.05)
-        loss.backward()
+        # L = mean|image - G| + 0.05 mean|depth - Gd|: value and gradients in ONE fused
+        # HIP launch, gradients handed to autograd (what loss.backward() would propagate)
+        loss = l1_image_depth_loss_backward(img, dep, gt_img, gt_dep, 0.05)
         if bucket is not None and exchange:
             if timed_exchange:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -626,7 +626,9 @@ int32_t mgs_mapping_loss_partial_count(int64_t num_pixels);
 /* Value and gradients of the mapping objective in one pass (upstream gradient 1 unless
  * grad_out is given): grad_image / grad_depth are written, `partial` receives the block sums
  * [4][*num_blocks_out] = colour residual, depth residual, d/da, d/db for a consumer that sums
- * them (mgs_pose_adam_step: loss_partials / exposure_partials). */
+ * them (mgs_pose_adam_step: loss_partials / exposure_partials).  With partial_ticket_ready != 0
+ * (the int at partial[4 n] zero when enqueued; restored by the call) the workgroup that finishes
+ * last also writes *loss, *grad_a, *grad_b (each optional). */
 int32_t mgs_mapping_loss_fused(const mgs_mapping_loss_args* args, int32_t* num_blocks_out, void* stream);
 int32_t mgs_mapping_view_iteration(const mgs_mapping_view_args* args, void* stream);
 

@@ -263,7 +263,7 @@ def lib():
     L.mgs_mapping_loss_partial_count.restype = C.c_int32
     L.mgs_mapping_loss_partial_count.argtypes = [C.c_int64]
     L.mgs_mapping_loss_fused.restype = C.c_int32
-    L.mgs_mapping_loss_fused.argtypes = [C.POINTER(MappingLossArgs), C.POINTER(C.c_int32), C.c_void_p]
+    L.mgs_mapping_loss_fused.argtypes = [C.POINTER(MappingLossArgs), C.c_void_p, C.c_void_p]
     L.mgs_mapping_view_iteration.restype = C.c_int32
     L.mgs_mapping_view_iteration.argtypes = [C.POINTER(MappingViewArgs), C.c_void_p]
     L.mgs_map_finish_iteration.restype = C.c_int32

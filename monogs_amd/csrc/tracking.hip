@@ -510,12 +510,36 @@ __global__ __launch_bounds__(kLossBlock) void k_map_loss_fused(mgs_mapping_loss_
   const float td = block_sum(sd, s_red);
   const float ta = block_sum(ga, s_red);
   const float tb = block_sum(gb, s_red);
+  const int n = gridDim.x;
+  if (threadIdx.x == 0) {   // write-through stores: see the hand-off below
+    __hip_atomic_store(&A.partial[blockIdx.x], tc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&A.partial[n + blockIdx.x], td, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&A.partial[2 * n + blockIdx.x], A.apply_exposure ? ta * sgn(a) : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&A.partial[3 * n + blockIdx.x], A.apply_exposure ? tb : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (!A.partial_ticket_ready) return;
+  // optional finish by the workgroup that arrives last (fence-free hand-off as in k_map_loss_fwd; the
+  // ticket is the int behind the 4 n partials, zero on entry, reset here): loss and exposure gradients
+  __shared__ int s_last;
   if (threadIdx.x == 0) {
-    const int n = gridDim.x;
-    A.partial[blockIdx.x] = tc;
-    A.partial[n + blockIdx.x] = td;
-    A.partial[2 * n + blockIdx.x] = A.apply_exposure ? ta * sgn(a) : 0.f;
-    A.partial[3 * n + blockIdx.x] = A.apply_exposure ? tb : 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int* ticket = reinterpret_cast<int*>(A.partial + 4 * n);
+    s_last = atomicAdd(ticket, 1) == n - 1;
+    if (s_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < n; i += kLossBlock)
+#pragma unroll
+    for (int c = 0; c < 4; c++) acc[c] += __hip_atomic_load(&A.partial[c * n + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  float tot[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) tot[c] = block_sum(acc[c], s_red);
+  if (threadIdx.x == 0) {
+    if (A.loss) A.loss[0] = A.w_rgb * tot[0] / (3.f * hw) + A.w_depth * tot[1] / hw;
+    if (A.grad_a) A.grad_a[0] = tot[2];
+    if (A.grad_b) A.grad_b[0] = tot[3];
   }
 }
 
@@ -659,7 +683,7 @@ int32_t mgs_mapping_loss_backward(const mgs_mapping_loss_args* a, void* stream) 
   return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
-int32_t mgs_mapping_loss_partial_count(int64_t num_pixels) { return 4 * loss_blocks(num_pixels); }
+int32_t mgs_mapping_loss_partial_count(int64_t num_pixels) { return 4 * loss_blocks(num_pixels) + 1; }
 
 // Single-pass form used by mgs_mapping_view_iteration; partial = [4][*nblk_out].
 int32_t mgs_mapping_loss_fused(const mgs_mapping_loss_args* a, int32_t* nblk_out, void* stream) {

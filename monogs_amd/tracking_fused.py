@@ -221,3 +221,49 @@ def l1_image_depth_loss(image, depth, gt_image, gt_depth, w_depth=0.05):
     BASELINE.md §4) through the same fused kernels."""
     return _MappingLoss.apply(image, depth, gt_image, gt_depth, None, None, None, 0.0, 1.0, w_depth,
                               -1.0, 0)
+
+
+def l1_image_depth_loss_backward(image, depth, gt_image, gt_depth, w_depth=0.05, *, mask=None, viewpoint=None,
+                                 w_rgb=1.0, depth_mask_threshold=-1.0):
+    """loss = w_rgb * mean|m (image' - gt)| + w_depth * mean|dm (depth - gt_depth)| AND its backward in
+    ONE kernel launch: value and gradients of an L1 objective do not depend on each other, so
+    `mgs_mapping_loss_fused` writes dL/dimage, dL/ddepth next to the block sums in a single pass, and
+    the gradients are handed to autograd directly (`torch.autograd.backward((image, depth), grads)` -
+    exactly what `loss.backward()` propagates for a scalar loss).  With `viewpoint` the exposure
+    (|a| + eps) image + b of utils/slam_utils.py:224-253 is applied and viewpoint.exposure_a/b receive
+    their gradients.  Returns the detached loss (a device scalar written by the same launch)."""
+    dev = image.device
+    if dev.type != "cuda":
+        raise RuntimeError("fused loss runs on the GPU only")
+    lib = _cabi.lib()
+    f = lambda t: None if t is None else t.detach().float().contiguous()
+    image_c, depth_c, gt_c, gtd_c, mask_c = f(image), f(depth), f(gt_image), f(gt_depth), f(mask)
+    HW = int(image_c.shape[-1] * image_c.shape[-2])
+    use_depth = w_depth != 0.0 and depth is not None
+    partial = _zeroed_partials(dev, int(lib.mgs_mapping_loss_partial_count(HW)))
+    g_img = torch.empty_like(image_c)
+    g_dep = torch.empty_like(depth_c) if use_depth else None
+    out = torch.empty(3, dtype=torch.float32, device=dev)        # loss, d/da, d/db
+    a = _cabi.MappingLossArgs()
+    ptr = lambda t: None if t is None else t.data_ptr()
+    a.image, a.gt, a.mask = ptr(image_c), ptr(gt_c), ptr(mask_c)
+    a.depth, a.gt_depth = (ptr(depth_c), ptr(gtd_c)) if use_depth else (None, None)
+    if viewpoint is not None:
+        a.exposure_a, a.exposure_b = viewpoint.exposure_a.data_ptr(), viewpoint.exposure_b.data_ptr()
+        a.exposure_eps, a.apply_exposure = float(viewpoint.exposure_eps), 1
+        a.grad_a, a.grad_b = out[1:].data_ptr(), out[2:].data_ptr()
+    a.w_rgb, a.w_depth = float(w_rgb), float(w_depth) if use_depth else 0.0
+    a.depth_mask_threshold, a.num_pixels = float(depth_mask_threshold), HW
+    a.partial, a.grad_image, a.grad_depth = partial.data_ptr(), g_img.data_ptr(), ptr(g_dep)
+    a.loss, a.partial_ticket_ready = out.data_ptr(), 1            # the last workgroup finishes the sums
+    _cabi.check(lib.mgs_mapping_loss_fused(C.byref(a), None, _stream(dev)), "mgs_mapping_loss_fused")
+    tensors, grads = [image], [g_img.view_as(image)]
+    if use_depth and depth.requires_grad:
+        tensors.append(depth)
+        grads.append(g_dep.view_as(depth))
+    torch.autograd.backward(tensors, grads)
+    if viewpoint is not None:
+        for p, g in ((viewpoint.exposure_a, out[1]), (viewpoint.exposure_b, out[2])):
+            if p.requires_grad:
+                p.grad = g.reshape(p.shape).clone() if p.grad is None else p.grad + g.reshape(p.shape)
+    return out[0]

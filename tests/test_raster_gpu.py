@@ -1246,3 +1246,49 @@ def test_tile_scan_handoff_never_reads_stale_counts(built):
         # the kernels' culling is conservative by a rounding slack: a handful of borderline pairs may differ
         assert (toff - want).abs().max().item() <= max(4, em.pairs // 2000)
     assert abs(int(toff[T]) - em.pairs) <= max(2, em.pairs // 1000)
+
+
+def test_fused_loss_backward_helper_matches_autograd(built):
+    """l1_image_depth_loss_backward: value + gradients in one launch, handed to autograd - equal to
+    loss.backward() of the torch formulation incl. the exposure path and the masks."""
+    from monogs_amd.tracking_fused import l1_image_depth_loss_backward
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    H, W = 75, 133
+
+    class VP:
+        pass
+    for use_vp in (False, True):
+        vp = None
+        if use_vp:
+            vp = VP()
+            vp.exposure_a = torch.tensor([-0.9], device=dev, requires_grad=True)
+            vp.exposure_b = torch.tensor([0.05], device=dev, requires_grad=True)
+            vp.exposure_eps = 1e-8
+        mask = (torch.rand(1, H, W, generator=g) > 0.3).float().to(dev) if use_vp else None
+        gi, gd = torch.rand(3, H, W, generator=g).to(dev), (torch.rand(1, H, W, generator=g) * 3).to(dev)
+        base_i, base_d = torch.rand(3, H, W, generator=g).to(dev), (torch.rand(1, H, W, generator=g) * 3).to(dev)
+        res = {}
+        for kind in ("torch", "fused"):
+            x = base_i.clone().requires_grad_()
+            y = base_d.clone().requires_grad_()
+            img, dep = x * 1.5 + 0.1, y * 0.7          # a graph in front, as the rasteriser would be
+            if vp is not None:
+                vp.exposure_a.grad = None
+                vp.exposure_b.grad = None
+            if kind == "torch":
+                im = img if vp is None else (torch.abs(vp.exposure_a) + vp.exposure_eps) * img + vp.exposure_b
+                m = 1.0 if mask is None else mask
+                dm = (gd > 0.5).float() if use_vp else 1.0
+                loss = 0.8 * torch.abs(m * (im - gi)).mean() + 0.3 * torch.abs(dm * (dep - gd)).mean()
+                loss.backward()
+            else:
+                loss = l1_image_depth_loss_backward(img, dep, gi, gd, 0.3, mask=mask, viewpoint=vp, w_rgb=0.8,
+                                                    depth_mask_threshold=0.5 if use_vp else -1.0)
+            res[kind] = (float(loss), x.grad.clone(), y.grad.clone(),
+                         None if vp is None else (vp.exposure_a.grad.clone(), vp.exposure_b.grad.clone()))
+        a, b = res["torch"], res["fused"]
+        assert abs(a[0] - b[0]) < 1e-5 * abs(a[0])
+        assert rel_err(b[1], a[1]) < 1e-5 and rel_err(b[2], a[2]) < 1e-5
+        if use_vp:
+            assert rel_err(b[3][0], a[3][0]) < 1e-4 and rel_err(b[3][1], a[3][1]) < 1e-4
