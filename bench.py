@@ -223,7 +223,9 @@ def main(argv=None):
                          f"--nproc-per-node {args.gpus} (or drop the launcher: bench.py starts the ranks itself)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # MGS_BENCH_FORCE_DIST=1: run the N-rank code path (process group, exchange, gathers) with whatever
+    # world the launcher gave, even 1 - the way to exercise the RCCL backend on a 1-GPU box
+    distributed = world > 1 or os.environ.get("MGS_BENCH_FORCE_DIST") == "1"
 
     import torch
     if not torch.cuda.is_available():
@@ -235,7 +237,7 @@ def main(argv=None):
     # the default-engine figure is reported next to it (`default_autograd_engine_fps`).
     torch.autograd.set_multithreading_enabled(False)
     ndev = max(1, torch.cuda.device_count())
-    shared_gpu = distributed and ndev < world
+    shared_gpu = world > 1 and ndev < world
     local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -276,6 +278,8 @@ def main(argv=None):
     ras = R.GaussianRasterizer(st)
     gt_img, gt_dep = sc.gt_image.to(dev), sc.gt_depth.to(dev)
     bucket = FlatGradBucket(params) if distributed else None
+    if bucket is not None and world == 1:
+        bucket.force_collective = True
     ex_events = []
 
     def step(exchange=True, timed_exchange=False):

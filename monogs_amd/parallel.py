@@ -89,8 +89,10 @@ class FlatGradBucket:
         self.pack(means2D_grad, radii)
         return self._reduce(group)
 
+    force_collective = False      # run the collectives even in a 1-rank group (backend smoke tests)
+
     def _reduce(self, group=None):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or self.force_collective):
             if dist.get_backend(group) == "gloo" and self.flat.is_cuda:
                 # CPU rehearsal of the exchange (tests / single-GPU dry runs): stage through
                 # host memory; the production path is RCCL on device buffers below

@@ -192,3 +192,21 @@ def test_native_mapper_sharded_over_two_ranks_matches_single_process(built):
 def _pose0(uid):
     from monogs_amd.parallel import view_pose
     return view_pose(uid).numpy()
+
+
+def test_bench_rccl_backend_with_a_one_rank_group(built):
+    """The box has one GPU, so RCCL cannot be run across ranks here; a 1-rank group still takes the
+    whole N-rank code path of bench.py on the `nccl` (= RCCL) backend: process group on the device,
+    pack + all_reduce(sum) + all_reduce(max), the gathers and the barriers."""
+    env = dict(os.environ, MGS_BENCH_FORCE_DIST="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MGS_DIST_BACKEND"):
+        env.pop(k, None)
+    port = 29500 + ((os.getpid() + 433) % 500)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "1", "--steps", "3", "--warmup", "1", "--gaussians", "20000", "--width", "320",
+                        "--height", "240", "--lean", "--profile-steps", "0"],
+                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["multi_gpu"]["backend"] == "rccl" and out["multi_gpu"]["exchange_ms"] > 0
