@@ -234,7 +234,7 @@ def main(argv=None):
     # a per-device worker thread; at ~0.37 ms of GPU work per step that hand-off is visible and
     # noisy (measured on one box: 0.38-0.53 ms/step with it, 0.367-0.370 without).  A PyTorch
     # runtime switch, not a change to what is computed (INTEGRATION.md recommends it for MonoGS);
-    # the default-engine figure is reported next to it (`default_autograd_engine_fps`).
+    # the mode is calibrated below and both figures are reported (`autograd_engine_calibration_fps`).
     torch.autograd.set_multithreading_enabled(False)
     ndev = max(1, torch.cuda.device_count())
     shared_gpu = world > 1 and ndev < world

@@ -12,7 +12,8 @@ def bench_mapping(sc, dev, iters: int = 10):
     """Mapping iterations/s for an 8-view window + 2 old keyframes (slam_backend.py:183-242) on the
     frozen-size SYN-C map (300k Gaussians @ 640x480): the reference-shaped Python body
     (slam_loops.mapping_step: autograd binding, fused loss, FusedGaussianAdam) against the native
-    one (mapping_native.NativeMapper: one C-ABI call per view)."""
+    one (mapping_native.NativeMapper: one C-ABI call per view) with 1, 2 (default) and 3 views in
+    flight on separate HIP streams."""
     import torch.nn as nn
     from .gaussian_model import GaussianModel
     from .mapping_native import NativeMapper
@@ -23,7 +24,7 @@ def bench_mapping(sc, dev, iters: int = 10):
     fovx, fovy = 2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy)
     bg = torch.zeros(3, device=dev)
     out = {"views_per_iteration": 10, "map": f"SYN-C map, {N} Gaussians @ {W}x{H}, window 8 + 2 old keyframes"}
-    for mode in ("python", "native"):
+    for mode in ("python", "native_1_stream", "native", "native_3_streams"):
         gm = GaussianModel(0, device=dev)
         gm._xyz = nn.Parameter(sc.means3D.to(dev).contiguous())
         gm._features_dc = nn.Parameter(sc.features_dc.to(dev).contiguous())
@@ -51,7 +52,9 @@ def bench_mapping(sc, dev, iters: int = 10):
                 gm.denom += o[2][:, None]
                 gm.max_radii2D = torch.maximum(gm.max_radii2D, o[3].float())
         else:
-            mp = NativeMapper(gm, bg, config={"Training": {"gaussian_update_every": 10 ** 9, "gaussian_reset": 10 ** 9}})
+            lanes = {"native_1_stream": 1, "native": 2, "native_3_streams": 3}[mode]
+            mp = NativeMapper(gm, bg, config={"Training": {"gaussian_update_every": 10 ** 9, "gaussian_reset": 10 ** 9}},
+                              concurrent_views=lanes)
             for i, v in enumerate(views):
                 mp.add_keyframe(i, v)
             mp.set_window(list(range(7, -1, -1)))
@@ -68,7 +71,7 @@ def bench_mapping(sc, dev, iters: int = 10):
         dt = time.perf_counter() - t0
         out[f"{mode}_iters_per_s"] = round(iters / dt, 2)
         out[f"{mode}_ms_per_view"] = round(dt / iters / 10 * 1e3, 4)
-        if mode == "native" and not mp.check_capacity():
+        if mode.startswith("native") and not mp.check_capacity():
             raise RuntimeError("native mapping bench overflowed its pair capacity")
     return out
 

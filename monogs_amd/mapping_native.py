@@ -82,9 +82,33 @@ class _ViewState:
         self.proj = f32(vp.projection_matrix)
 
 
+class _Lane:
+    """Everything one in-flight view needs for itself: a HIP stream, the rasteriser workspaces and
+    outputs, its accumulation buffer and its pair-count slots.  The views of a mapping iteration
+    are independent until the optimiser step, so NativeMapper keeps `concurrent_views` of them in
+    flight on different streams: the latency-bound front-end kernels and the low-occupancy tails of
+    the blend kernels of one view overlap with the other view's work."""
+
+    def __init__(self, dev, stream):
+        self.dev, self.stream = dev, stream            # stream None: torch's current stream
+        self.host_D = torch.zeros(2, dtype=torch.int32).pin_memory()      # [0] = D, [1] = fullest tile
+        self.d_max = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.loss_accum = torch.zeros(1, device=dev)
+        self.shape_key, self.cap_alloc = None, 0
+        self.flat = self.radii_max = self.radii = self.n_touched = None
+        self.event = torch.cuda.Event()
+
+    def torch_stream(self):
+        return self.stream if self.stream is not None else torch.cuda.current_stream(self.dev)
+
+    def stream_ptr(self):
+        return C.c_void_p(self.torch_stream().cuda_stream)
+
+
 class NativeMapper:
     def __init__(self, gaussians: GaussianModel, background, config: Optional[dict] = None,
-                 cameras_extent: float = 6.0, group=None, capacity_margin: float = 1.5, seed: int = 0):
+                 cameras_extent: float = 6.0, group=None, capacity_margin: float = 1.5, seed: int = 0,
+                 concurrent_views: int = 2):
         cfg = {k: dict(v) for k, v in DEFAULT_MAP_CONFIG.items()}
         for k, v in (config or {}).items():
             if isinstance(v, dict):
@@ -113,9 +137,9 @@ class NativeMapper:
         self.capacity = 0
         self._N = -1
         self._shape_key = None
-        self._host_D = torch.zeros(2, dtype=torch.int32).pin_memory()      # [0] = D, [1] = fullest tile
-        self._d_max = torch.zeros(1, dtype=torch.int32, device=self.dev)
-        self.loss_accum = torch.zeros(1, device=self.dev)
+        self.lanes = [_Lane(self.dev, None)] + [_Lane(self.dev, torch.cuda.Stream(device=self.dev))
+                                                for _ in range(max(1, int(concurrent_views)) - 1)]
+        self.loss_accum = self.lanes[0].loss_accum
         self.last_loss = None
         self.overflow_regrows = 0
 
@@ -145,15 +169,20 @@ class NativeMapper:
             self.off[name] = (off, N * w)
             off += _align(N * w)
         if N != self._N:
-            self.flat = torch.zeros(off, device=dev)
-            self.radii_max = torch.zeros(N, dtype=torch.int32, device=dev)
+            if len(self.lanes) > 1:
+                torch.cuda.synchronize(self.dev)        # buffers of other streams are about to be replaced
+            for ln in self.lanes:
+                with torch.cuda.stream(ln.torch_stream()):   # the caching allocator ties a block to its stream
+                    ln.flat = torch.zeros(off, device=dev)
+                    ln.radii_max = torch.zeros(N, dtype=torch.int32, device=dev)
+                    ln.radii = torch.empty(N, dtype=torch.int32, device=dev)
+                    ln.n_touched = torch.empty(N, dtype=torch.int32, device=dev)
+                ln.shape_key = None             # geom depends on N
+            self.flat, self.radii_max = self.lanes[0].flat, self.lanes[0].radii_max
             self.scales = torch.empty(N, 3, device=dev)
             self.rots = torch.empty(N, 4, device=dev)
             self.opac = torch.empty(N, device=dev)
             self.shs = torch.empty(N, K, 3, device=dev) if K > 1 else None
-            self.radii = torch.empty(N, dtype=torch.int32, device=dev)
-            self.n_touched = torch.empty(N, dtype=torch.int32, device=dev)
-            self._shape_key = None              # geom depends on N
             self._need_probe = True
         self._N = N
         self._param_ptrs = tuple(getattr(g, a).data_ptr() for a in ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest"))
@@ -164,31 +193,38 @@ class NativeMapper:
             o, n = self.off[name]
             self._grad_views[attr] = self.flat[o:o + n].view_as(getattr(g, attr))
 
-    def _section(self, name):
+    def _section(self, name, lane=None):
         o, n = self.off[name]
-        return self.flat[o:o + n]
+        return (self.lanes[0] if lane is None else lane).flat[o:o + n]
 
-    def _ensure_workspaces(self, W, H, deg):
+    def _ensure_workspaces(self, ln, W, H, deg):
+        with torch.cuda.stream(ln.torch_stream()):
+            self._alloc_workspaces(ln, W, H, deg)
+        if ln is self.lanes[0]:      # the last render of lane 0 is what callers look at
+            self.color, self.depth, self.opacity = ln.color, ln.depth, ln.opacity
+            self.radii, self.n_touched = ln.radii, ln.n_touched
+
+    def _alloc_workspaces(self, ln, W, H, deg):
         key = (self._N, W, H, self.K)
-        if key != self._shape_key:
+        if key != ln.shape_key:
             shape = _cabi.RasterShape(self._N, W, H, deg, self.K, max(self.capacity, 1024), 1.0, 1.0, 1.0)
             sizes = _cabi.workspace_sizes(shape)
-            self.geom = torch.empty(int(sizes.geom_bytes), dtype=torch.uint8, device=self.dev)
-            self.color = torch.empty(3, H, W, device=self.dev)
-            self.depth = torch.empty(1, H, W, device=self.dev)
-            self.opacity = torch.empty(1, H, W, device=self.dev)
-            self.grad_image = torch.empty(3, H, W, device=self.dev)
-            self.grad_depth = torch.empty(1, H, W, device=self.dev)
-            self.grad_tau = torch.zeros(6, device=self.dev)
-            self.loss_partial = torch.empty(int(_cabi.lib().mgs_mapping_loss_partial_count(H * W)), device=self.dev)
-            self._shape_key = key
-            self._cap_alloc = 0
-        if self._cap_alloc != self.capacity:
+            ln.geom = torch.empty(int(sizes.geom_bytes), dtype=torch.uint8, device=self.dev)
+            ln.color = torch.empty(3, H, W, device=self.dev)
+            ln.depth = torch.empty(1, H, W, device=self.dev)
+            ln.opacity = torch.empty(1, H, W, device=self.dev)
+            ln.grad_image = torch.empty(3, H, W, device=self.dev)
+            ln.grad_depth = torch.empty(1, H, W, device=self.dev)
+            ln.grad_tau = torch.zeros(6, device=self.dev)
+            ln.loss_partial = torch.empty(int(_cabi.lib().mgs_mapping_loss_partial_count(H * W)), device=self.dev)
+            ln.shape_key = key
+            ln.cap_alloc = 0
+        if ln.cap_alloc != self.capacity:
             shape = _cabi.RasterShape(self._N, W, H, deg, self.K, self.capacity, 1.0, 1.0, 1.0)
             sizes = _cabi.workspace_sizes(shape)
-            self.bins = torch.empty(int(sizes.bins_bytes), dtype=torch.uint8, device=self.dev)
-            self.bwd = torch.empty(int(sizes.bwd_bytes), dtype=torch.uint8, device=self.dev)
-            self._cap_alloc = self.capacity
+            ln.bins = torch.empty(int(sizes.bins_bytes), dtype=torch.uint8, device=self.dev)
+            ln.bwd = torch.empty(int(sizes.bwd_bytes), dtype=torch.uint8, device=self.dev)
+            ln.cap_alloc = self.capacity
 
     # ---- window / optimiser set-up (the "keyframe" message, :427-489) ------------------------------------
     def add_keyframe(self, kf_idx: int, viewpoint):
@@ -208,11 +244,12 @@ class NativeMapper:
 
     # ---- one view ----------------------------------------------------------------------------------
     def _view_args(self, kf_idx, cam_idx, *, accumulate, add_reg, initialization=False, forward_only=False,
-                   in_window=True, stats=True):
+                   in_window=True, stats=True, lane=None):
         vp, st, g = self.viewpoints[kf_idx], self.states[kf_idx], self.gaussians
         tr = self.cfg["Training"]
+        ln = self.lanes[0] if lane is None else lane
         W, H = int(vp.image_width), int(vp.image_height)
-        self._ensure_workspaces(W, H, int(g.active_sh_degree))
+        self._ensure_workspaces(ln, W, H, int(g.active_sh_degree))
         a = _cabi.MappingViewArgs()
         f = a.fwd
         f.shape = _cabi.RasterShape(self._N, W, H, int(g.active_sh_degree), self.K, self.capacity,
@@ -222,13 +259,13 @@ class NativeMapper:
         f.shs = g._features_dc.data_ptr() if self.K == 1 else self.shs.data_ptr()
         f.viewmatrix, f.projmatrix, f.projmatrix_raw = st.view.data_ptr(), st.full.data_ptr(), st.proj.data_ptr()
         f.campos, f.bg = st.view.data_ptr(), self.bg.data_ptr()
-        f.geom, f.bins = self.geom.data_ptr(), self.bins.data_ptr()
-        f.out_color, f.out_depth, f.out_opacity = self.color.data_ptr(), self.depth.data_ptr(), self.opacity.data_ptr()
-        f.radii, f.n_touched = self.radii.data_ptr(), self.n_touched.data_ptr()
-        f.pair_count_out, f.pair_count_max = self._host_D.data_ptr(), self._d_max.data_ptr()
-        f.big_tile_pass = -1 if 0 < int(self._host_D[1]) <= 900 else 0
-        a.bwd, a.grad_image, a.grad_tau = self.bwd.data_ptr(), self.grad_image.data_ptr(), self.grad_tau.data_ptr()
-        a.grad_depth = self.grad_depth.data_ptr()
+        f.geom, f.bins = ln.geom.data_ptr(), ln.bins.data_ptr()
+        f.out_color, f.out_depth, f.out_opacity = ln.color.data_ptr(), ln.depth.data_ptr(), ln.opacity.data_ptr()
+        f.radii, f.n_touched = ln.radii.data_ptr(), ln.n_touched.data_ptr()
+        f.pair_count_out, f.pair_count_max = ln.host_D.data_ptr(), ln.d_max.data_ptr()
+        f.big_tile_pass = -1 if 0 < int(ln.host_D[1]) <= 900 else 0
+        a.bwd, a.grad_image, a.grad_tau = ln.bwd.data_ptr(), ln.grad_image.data_ptr(), ln.grad_tau.data_ptr()
+        a.grad_depth = ln.grad_depth.data_ptr()
         # objective (utils/slam_utils.py:224-253)
         L = a.loss
         L.gt = st.gt.data_ptr()
@@ -246,7 +283,7 @@ class NativeMapper:
         L.depth_mask_threshold = 0.01
         L.apply_exposure = 0 if initialization else 1
         L.num_pixels = H * W
-        L.partial = self.loss_partial.data_ptr()
+        L.partial = ln.loss_partial.data_ptr()
         # this view's optimiser (:452-489): pose deltas for the first frames_to_optimize window views,
         # exposure for every window view; keyframe 0 is the fixed reference; extra views: none
         A = a.adam
@@ -269,19 +306,19 @@ class NativeMapper:
         if not forward_only:
             st.step += 1
         A.step = max(1, st.step)
-        a.loss_view, a.loss_accum = st.loss.data_ptr(), self.loss_accum.data_ptr()
+        a.loss_view, a.loss_accum = st.loss.data_ptr(), ln.loss_accum.data_ptr()
         a.camera_matrices_valid = 1 if st.matrices_fresh else 0
         a.forward_only = 1 if forward_only else 0
         # accumulation target: the flat gradient buffer (+ statistics of this view)
         M = a.accum
         M.scale_dims, M.accumulate, M.add_regulariser, M.regulariser_weight = self.sd, int(accumulate), int(add_reg), 10.0
         M.raw_rotations = g._rotation.data_ptr()
-        ptr = lambda name: self._section(name).data_ptr()
+        ptr = lambda name: self._section(name, ln).data_ptr()
         M.grad_xyz, M.grad_features_dc, M.grad_opacity = ptr("xyz"), ptr("f_dc"), ptr("opacity")
         M.grad_features_rest = ptr("f_rest") if self.K > 1 else None
         M.grad_scaling, M.grad_rotation = ptr("scaling"), ptr("rotation")
         if stats:
-            M.gradnorm_inc, M.denom_inc, M.radii_max = ptr("gradnorm"), ptr("denom"), self.radii_max.data_ptr()
+            M.gradnorm_inc, M.denom_inc, M.radii_max = ptr("gradnorm"), ptr("denom"), ln.radii_max.data_ptr()
         if in_window:
             vis = self.occ_aware_visibility.get(kf_idx)
             if vis is None or vis.shape[0] != self._N:
@@ -300,29 +337,58 @@ class NativeMapper:
                                              st.full.data_ptr(), self._stream()), "mgs_camera_from_pose")
         _cabi.check(lib.mgs_raster_forward_project(C.byref(a.fwd), self._stream()), "mgs_raster_forward_project")
         torch.cuda.current_stream(self.dev).synchronize()
-        D = int(self._host_D[0].item())
-        self._d_max.zero_()
+        D = int(self.lanes[0].host_D[0].item())
+        self.lanes[0].d_max.zero_()
         self.capacity = max(self.capacity, 1024, (int(D * self.capacity_margin) + 1023) // 1024 * 1024)
         self._need_probe = False
 
-    def _run_view(self, kf_idx, cam_idx, **kw):
+    def _run_view(self, kf_idx, cam_idx, lane=None, **kw):
         if self._need_probe:
             self._probe_capacity(kf_idx)
+        ln = self.lanes[0] if lane is None else lane
         # D of an earlier view lands in pinned host memory without a sync: grow BEFORE it overflows
-        seen = int(self._host_D[0].item())
+        seen = max(int(l.host_D[0].item()) for l in self.lanes)
         if seen > 0.9 * self.capacity:
+            if len(self.lanes) > 1:
+                torch.cuda.synchronize(self.dev)        # workspaces of other streams are about to be replaced
             self.capacity = (int(seen * self.capacity_margin) + 1023) // 1024 * 1024
             self.overflow_regrows += 1
-        a, st = self._view_args(kf_idx, cam_idx, **kw)
-        _cabi.check(_cabi.lib().mgs_mapping_view_iteration(C.byref(a), self._stream()), "mgs_mapping_view_iteration")
+        a, st = self._view_args(kf_idx, cam_idx, lane=ln, **kw)
+        _cabi.check(_cabi.lib().mgs_mapping_view_iteration(C.byref(a), ln.stream_ptr()), "mgs_mapping_view_iteration")
         st.matrices_fresh = not kw.get("forward_only", False)   # the Adam kernel wrote the updated matrices
-        self._keep = a
+        ln.keep = a
 
     def check_capacity(self) -> bool:
         """True iff every forward since the last check was rendered completely (host sync)."""
-        worst = int(self._d_max.item())
-        self._d_max.zero_()
+        worst = max(int(l.d_max.item()) for l in self.lanes)
+        for l in self.lanes:
+            l.d_max.zero_()
         return worst <= self.capacity
+
+    def _fan_out(self, jobs, rank, prune):
+        """Enqueue this rank's views of one iteration round-robin over the lanes and fold the lanes'
+        accumulators into lane 0 (the buffer the optimiser and the all-reduce read)."""
+        L = self.lanes
+        used = L[:max(1, min(len(L), len(jobs)))]
+        main = torch.cuda.current_stream(self.dev)
+        if len(used) > 1:                      # the other streams start behind the activation kernel
+            L[0].event.record(main)
+            for ln in used[1:]:
+                ln.stream.wait_event(L[0].event)
+        for n, (gi, (kf, ci, inw)) in enumerate(jobs):
+            ln = used[n % len(used)]
+            if n < len(used) and ln is not L[0]:
+                with torch.cuda.stream(ln.stream):
+                    ln.loss_accum.zero_()
+            self._run_view(kf, ci, lane=ln, accumulate=n >= len(used), add_reg=(n == 0 and rank == 0), in_window=inw,
+                           forward_only=prune, stats=not prune)
+        for ln in used[1:]:                    # join, then fold
+            ln.event.record(ln.stream)
+            main.wait_event(ln.event)
+            if not prune:
+                torch.add(L[0].flat, ln.flat, out=L[0].flat)
+                torch.maximum(L[0].radii_max, ln.radii_max, out=L[0].radii_max)
+                L[0].loss_accum += ln.loss_accum
 
     # ---- map() (:157-333) -------------------------------------------------------------------------------------
     def _shard(self, items):
@@ -399,9 +465,7 @@ class NativeMapper:
             if not jobs:
                 self.flat.zero_()
                 self.radii_max.zero_()
-            for n, (gi, (kf, ci, inw)) in enumerate(jobs):
-                self._run_view(kf, ci, accumulate=n > 0, add_reg=(n == 0 and rank == 0), in_window=inw,
-                               forward_only=prune, stats=not prune)
+            self._fan_out(jobs, rank, prune)
             if prune:
                 self._prune_pass(window, world)
                 return False
