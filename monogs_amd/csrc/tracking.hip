@@ -74,30 +74,53 @@ __global__ __launch_bounds__(512) void k_pose_adam_update(mgs_pose_adam_args A) 
     if (A.loss_view) A.loss_view[0] = l;
     if (A.loss_accum) A.loss_accum[0] += l;
   }
+  // One thread, ~60 scalars of state: every load is issued BEFORE the first store (a store in
+  // between makes the compiler re-load what may alias, and each dependent global round trip costs
+  // ~1 us here: this kernel went 14.7 -> 10.7 us with the loads batched, profiles/r02_tracking_profile.txt).
   float* P[4] = {A.cam_rot_delta, A.cam_trans_delta, A.exposure_a, A.exposure_b};
   const float* G[4] = {A.tau_partials ? &s_g[0] : A.grad_rot, A.tau_partials ? &s_g[3] : A.grad_trans,
                        A.exposure_partials ? (A.exposure_a ? &s_g[6] : nullptr) : A.grad_a,
                        A.exposure_partials ? (A.exposure_b ? &s_g[7] : nullptr) : A.grad_b};
   const float lr[4] = {A.lr_rot, A.lr_trans, A.lr_a, A.lr_b};
-  const int len[4] = {3, 3, 1, 1};
+  constexpr int first[4] = {0, 3, 6, 7}, len[4] = {3, 3, 1, 1};
+  float p[8], gr[8], m[8], v[8], Tm[16], proj[16];
+  bool on[8];
+#pragma unroll
+  for (int g = 0; g < 4; g++)
+#pragma unroll
+    for (int i = 0; i < len[g]; i++) {
+      const int o = first[g] + i;
+      on[o] = G[g] != nullptr && P[g] != nullptr;
+      p[o] = P[g] ? P[g][i] : 0.f;
+      gr[o] = on[o] ? G[g][i] : 0.f;
+      m[o] = A.exp_avg[o];
+      v[o] = A.exp_avg_sq[o];
+    }
+  const bool have_T = A.T != nullptr;
+  const bool want_mats = have_T && A.viewmatrix_out && A.projmatrix_out && A.projection;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    Tm[i] = have_T ? A.T[i] : 0.f;
+    proj[i] = want_mats ? A.projection[i] : 0.f;
+  }
   const float bc1 = 1.f - powf(A.beta1, (float)A.step);
   const float bc2s = sqrtf(1.f - powf(A.beta2, (float)A.step));
-  int off = 0;
-  for (int g = 0; g < 4; g++) {
-    for (int i = 0; i < len[g]; i++, off++) {
-      if (!G[g] || !P[g]) continue;
-      const float gr = G[g][i];
-      const float m = A.beta1 * A.exp_avg[off] + (1.f - A.beta1) * gr;
-      const float v = A.beta2 * A.exp_avg_sq[off] + (1.f - A.beta2) * gr * gr;
-      A.exp_avg[off] = m; A.exp_avg_sq[off] = v;
-      const float denom = sqrtf(v) / bc2s + A.eps;
-      P[g][i] -= (lr[g] / bc1) * (m / denom);
+#pragma unroll
+  for (int g = 0; g < 4; g++)
+#pragma unroll
+    for (int i = 0; i < len[g]; i++) {
+      const int o = first[g] + i;
+      if (!on[o]) continue;
+      m[o] = A.beta1 * m[o] + (1.f - A.beta1) * gr[o];
+      v[o] = A.beta2 * v[o] + (1.f - A.beta2) * gr[o] * gr[o];
+      const float denom = sqrtf(v[o]) / bc2s + A.eps;
+      p[o] -= (lr[g] / bc1) * (m[o] / denom);
     }
-  }
-  if (A.T) {
-    const bool move = !A.no_pose_update && A.cam_rot_delta && A.cam_trans_delta;
-    const float th[3] = {move ? A.cam_rot_delta[0] : 0.f, move ? A.cam_rot_delta[1] : 0.f, move ? A.cam_rot_delta[2] : 0.f};
-    const float rho[3] = {move ? A.cam_trans_delta[0] : 0.f, move ? A.cam_trans_delta[1] : 0.f, move ? A.cam_trans_delta[2] : 0.f};
+  // pose update from the stepped deltas (registers)
+  const bool move = have_T && !A.no_pose_update && A.cam_rot_delta && A.cam_trans_delta;
+  const float th[3] = {move ? p[0] : 0.f, move ? p[1] : 0.f, move ? p[2] : 0.f};
+  const float rho[3] = {move ? p[3] : 0.f, move ? p[4] : 0.f, move ? p[5] : 0.f};
+  if (move) {
     float R[9], V[9];
     so3_exp_V(th, R, V);
     float t[3];
@@ -105,20 +128,32 @@ __global__ __launch_bounds__(512) void k_pose_adam_update(mgs_pose_adam_args A) 
     float Tn[12];
     for (int i = 0; i < 3; i++)
       for (int j = 0; j < 4; j++)
-        Tn[4 * i + j] = R[3 * i] * A.T[j] + R[3 * i + 1] * A.T[4 + j] + R[3 * i + 2] * A.T[8 + j] +
-                        (j == 3 ? t[i] : 0.f) * A.T[15];
-    if (move) for (int i = 0; i < 12; i++) A.T[i] = Tn[i];
+        Tn[4 * i + j] = R[3 * i] * Tm[j] + R[3 * i + 1] * Tm[4 + j] + R[3 * i + 2] * Tm[8 + j] +
+                        (j == 3 ? t[i] : 0.f) * Tm[15];
+    for (int i = 0; i < 12; i++) Tm[i] = Tn[i];
+    for (int i = 0; i < 6; i++) p[i] = 0.f;           // deltas are consumed by update_pose
+  }
+  // ---- stores ----
+#pragma unroll
+  for (int g = 0; g < 4; g++)
+#pragma unroll
+    for (int i = 0; i < len[g]; i++) {
+      const int o = first[g] + i;
+      if (on[o]) { A.exp_avg[o] = m[o]; A.exp_avg_sq[o] = v[o]; }
+      if (on[o] || (move && o < 6)) P[g][i] = p[o];     // applied deltas are zeroed even without a step
+    }
+  if (have_T) {
+    if (move) for (int i = 0; i < 12; i++) A.T[i] = Tm[i];
     const float n2 = th[0] * th[0] + th[1] * th[1] + th[2] * th[2] + rho[0] * rho[0] + rho[1] * rho[1] +
                      rho[2] * rho[2];
     if (A.converged) *A.converged = n2 < A.converged_threshold * A.converged_threshold ? 1 : 0;
-    if (move) for (int i = 0; i < 3; i++) { A.cam_rot_delta[i] = 0.f; A.cam_trans_delta[i] = 0.f; }
-    if (A.viewmatrix_out && A.projmatrix_out && A.projection) {   // matrices of the updated pose
+    if (want_mats) {   // matrices of the updated pose: view = T^T, full = view @ projection
       for (int i = 0; i < 4; i++)
         for (int j = 0; j < 4; j++) {
           float acc = 0.f;
-          for (int k = 0; k < 4; k++) acc += A.T[4 * k + i] * A.projection[4 * k + j];
+          for (int k = 0; k < 4; k++) acc += Tm[4 * k + i] * proj[4 * k + j];
           A.projmatrix_out[4 * i + j] = acc;
-          A.viewmatrix_out[4 * i + j] = A.T[4 * j + i];
+          A.viewmatrix_out[4 * i + j] = Tm[4 * j + i];
         }
     }
   }
