@@ -100,9 +100,15 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : (POSE ? 5 : 6)) void k_blend_bwd(K
   if (item >= min(P.seg_offset[P.T], P.max_segs)) return;
   // One 16-B record per item (written by the tile sort) instead of a chain of dependent loads:
   // tile, index of the item's first key, number of splats (<= kItem), position in the tile's list.
+#if defined(MGS_BPRIO)
+  __builtin_amdgcn_s_setprio(MGS_BPRIO == 1 ? 3 : 0);
+#endif
   const int4 sr = P.seg_rec[item];
   const int tile = sr.x, k0 = sr.y, nb = sr.z, base = sr.w;
   if (nb <= 0) return;
+#if defined(MGS_ABL) && MGS_ABL == 10
+  return;
+#endif
   __builtin_assume(nb <= kItem);
   const int tx = tile % P.grid_x, ty = tile / P.grid_x;
   // Pixel q of this lane lies in QUADRANT q of the tile: (qx + 8 (q & 1), qy + 8 (q >> 1)).
@@ -170,6 +176,11 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : (POSE ? 5 : 6)) void k_blend_bwd(K
     if (last[q] <= base) { T[q] = 0.f; gS[q] = 0.f; }
   }
   const int tile_last = max(max(qlast[0], qlast[1]), max(qlast[2], qlast[3]));
+#if defined(MGS_ABL) && MGS_ABL == 11
+  if (T[0] + T[1] + T[2] + T[3] + gS[0] + gS[1] + gS[2] + gS[3] + g0[0] + g0[1] + g0[2] + g0[3] == 123.456f && lo_next == 77u)
+    B.pair_grad[lane].x = (float)(last[0] + last[1] + last[2] + last[3] + tile_last);
+  return;
+#endif
 
   // sketch mode: per-pixel pose-Jacobian rows of this item, as pairs (tau 0,1) (2,3) (4,5)
   v2f J2[SKETCH ? 4 : 1][3];
@@ -340,8 +351,12 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : (POSE ? 5 : 6)) void k_blend_bwd(K
       // unrolled with the NEXT splat's record prefetched from LDS above the arithmetic of the
       // current one, so that no LDS latency sits between two splats and no registers rotate.
       unsigned long long todo = mq[0] | mq[1] | mq[2] | mq[3];
-#if defined(MGS_ABL) && MGS_ABL == 4
+#if defined(MGS_BPRIO)
+      __builtin_amdgcn_s_setprio(MGS_BPRIO == 1 ? 0 : 3);
+#endif
+#if defined(MGS_ABL) && (MGS_ABL == 4 || MGS_ABL == 12)
       todo = 0ull;
+      T[0] += s_r0[lane ^ 1].x + s_r1[lane ^ 1].y + s_r2[lane ^ 1].x + (float)(mq[0] + mq[1] + mq[2] + mq[3]);
 #endif
       if (todo != 0ull) {
         int j0 = __builtin_ctzll(todo);
@@ -365,7 +380,12 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : (POSE ? 5 : 6)) void k_blend_bwd(K
       }
     }
     // splats of the segment that no pixel reached: zero record
-    if (!JONLY && slot >= 0 && !((written >> lane) & 1ull)) {
+#if defined(MGS_ABL) && MGS_ABL == 12
+    if (slot == 0x7fffffff)
+#else
+    if (!JONLY && slot >= 0 && !((written >> lane) & 1ull))
+#endif
+    {
       float4* dst = B.pair_grad + (size_t)slot * 3;
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       dst[0] = z; dst[1] = z; dst[2] = z;

@@ -317,6 +317,7 @@ __global__ __launch_bounds__(256) void k_scan_write(KP P) {
 // ---------------------------------------------------------------------------------
 // Exclusive scans of the T tile counts (-> tile_offset, D) and of the per-tile segment
 // backward item counts ceil(n_t / kItem) (-> seg_offset) by one 1024-thread workgroup.
+constexpr int kOrderClasses = 128, kOrderStep = 32;
 __device__ __forceinline__ void tile_scan_body(const KP& P, int nbin, int* s_sum, int* s_seg) {
   __shared__ int s_tmax;
   const int tid = threadIdx.x;
@@ -381,6 +382,36 @@ __device__ __forceinline__ void tile_scan_body(const KP& P, int nbin, int* s_sum
     }
     P.counters[1] = s_seg[1023];
     if (P.d_max) atomicMax(P.d_max, s_sum[1023]);
+  }
+  // Launch order of the forward blend: tiles by decreasing list length (counting sort on
+  // n / kOrderStep, longest class first; the order inside a class is arbitrary and irrelevant).
+  // All 4T quadrant waves are resident at once and the dispatcher deals consecutive workgroups
+  // round-robin, so every SIMD gets one wave of each length class instead of a random draw.
+  __syncthreads();
+  int* s_hist = s_seg;
+  if (tid < kOrderClasses) s_hist[tid] = 0;
+  __syncthreads();
+  for (int i = lo; i < hi; i++) {
+    const int c = __hip_atomic_load(&P.tile_count[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    atomicAdd(&s_hist[kOrderClasses - 1 - min(kOrderClasses - 1, c / kOrderStep)], 1);
+  }
+  __syncthreads();
+  if (tid < 64) {    // exclusive scan of the class sizes by one wave (kOrderClasses = 2 x 64)
+    static_assert(kOrderClasses == 128, "two classes per lane");
+    const int a = s_hist[2 * tid], b = s_hist[2 * tid + 1];
+    int incl = a + b;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(incl, off);
+      if (tid >= off) incl += t;
+    }
+    s_hist[2 * tid] = incl - a - b;
+    s_hist[2 * tid + 1] = incl - b;
+  }
+  __syncthreads();
+  for (int i = lo; i < hi; i++) {
+    const int c = __hip_atomic_load(&P.tile_count[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    P.tile_order[atomicAdd(&s_hist[kOrderClasses - 1 - min(kOrderClasses - 1, c / kOrderStep)], 1)] = i;
   }
 }
 
@@ -635,6 +666,7 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(KP P) {
 // of a pixel whose n_contrib lies in front of the item).
 constexpr float kLog2e = 1.4426950408889634f;
 typedef float v2f __attribute__((ext_vector_type(2)));
+constexpr int kFwdPrioStep = 128;  // splats of remaining list per s_setprio level
 constexpr int kFwdChunk = 4;       // the four quadrants of a tile share an XCD (same records)
 static_assert(kSeg == 64, "one staged record per lane");
 
@@ -652,34 +684,50 @@ __device__ __forceinline__ void mask_clear_bit(unsigned long long& m, int j) {
 
 #ifdef MGS_STAMP   // diagnostic build only (profiles/stamp_forward.py): per-workgroup start/end stamps
 __device__ long long g_stamps[4 * 65536];
+__device__ long long g_phase[4 * 65536];
+extern "C" int mgs_debug_read_phases(long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_phase), sizeof(long long) * n);
+}
 extern "C" int mgs_debug_read_stamps(long long* host, int n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(long long) * n);
 }
 struct StampScope {
   long long t0, c0;
-  __device__ StampScope() : t0(__builtin_amdgcn_s_memrealtime()), c0(__builtin_amdgcn_s_memtime()) {}
+  int nseg = 0, nvisit = 0;
+  long long ph[4] = {0, 0, 0, 0}, tl = 0;
+  __device__ void mark(int k) { const long long t = __builtin_amdgcn_s_memtime(); ph[k] += t - tl; tl = t; }
+  __device__ StampScope() : t0(__builtin_amdgcn_s_memrealtime()), c0(__builtin_amdgcn_s_memtime()) { tl = c0; }
   __device__ ~StampScope() {
     if (threadIdx.x == 0 && blockIdx.x < 65536) {
       g_stamps[4 * blockIdx.x + 0] = t0;
       g_stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-      g_stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime() - c0;
+      g_stamps[4 * blockIdx.x + 2] = ((__builtin_amdgcn_s_memtime() - c0) & 0xFFFFFFll) | ((long long)nseg << 24) | ((long long)nvisit << 40);
       g_stamps[4 * blockIdx.x + 3] = ((long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32) |
                                      __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+      for (int k = 0; k < 4; k++) g_phase[4 * blockIdx.x + k] = ph[k];
     }
   }
 };
 #define MGS_STAMP_SCOPE StampScope stamp_scope_
+#define MGS_STAMP_SEG(m) (stamp_scope_.nseg++, stamp_scope_.nvisit += __popcll(m))
+#define MGS_MARK(k) stamp_scope_.mark(k)
 #else
+#define MGS_MARK(k)
 #define MGS_STAMP_SCOPE
+#define MGS_STAMP_SEG(m)
 #endif
 
 __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
   MGS_STAMP_SCOPE;
-  // per staged splat 48 B: (x, y, A', B') (C', opacity, r, g) (b, depth, -, -)
+  // per staged splat 48 B: (a0, a1, a2, A) (B, C, opacity, -) (r, g, b, depth)
   __shared__ float4 s_rec[kSeg * 3];
   const int item = xcd_remap<kFwdChunk>(blockIdx.x);
   if (item >= 4 * P.T) return;
+#if defined(MGS_NO_ORDER)
   const int tile = item >> 2, quad = item & 3, lane = threadIdx.x;
+#else
+  const int tile = P.tile_order[item >> 2], quad = item & 3, lane = threadIdx.x;
+#endif
   const int tx = tile % P.grid_x, ty = tile / P.grid_x;
   const int qx0 = tx * kTile + 8 * (quad & 1), qy0 = ty * kTile + 8 * (quad >> 1);
   if (qx0 >= P.W || qy0 >= P.H) return;                  // quadrant outside the image
@@ -693,11 +741,16 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
   // this quadrant's pixel-centre box, clipped to the image
   const float bx0 = (float)qx0, by0 = (float)qy0;
   const float bx1 = fminf(bx0 + 7.f, (float)(P.W - 1)), by1 = fminf(by0 + 7.f, (float)(P.H - 1));
-  float live = inside ? 1.f : 0.f;
-  float T = 1.f;
+  // T > 0: transmittance of a live pixel (T >= kTStop is invariant).  A pixel that has saturated -
+  // or lies outside the image - keeps its transmittance with the SIGN flipped: T (1 - alpha) is
+  // then negative, "test_T < kTStop" fires again at every later splat and nothing is blended, so
+  // no separate live flag is carried through the visit.
+  float T = inside ? 1.f : -1.f;
+  // pixel offset from the quadrant centre: the exponent is evaluated as a polynomial in it
+  const float xh = (float)(lane & 7) - 3.5f, yh = (float)(lane >> 3) - 3.5f;
+  const float qcx = (float)qx0 + 3.5f, qcy = (float)qy0 + 3.5f;
   v2f C01 = {0.f, 0.f}, C2D = {0.f, 0.f};     // (C0, C1), (C2, depth): packed-FMA operands
   int last = 0;
-  const float fpx = (float)px, fpy = (float)py;
 
   // pipeline prologue: ids of segments 0 and 1, records of segment 0
   // (ids default to 0, a valid record, so the record loads need no branch)
@@ -707,90 +760,108 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
   float4 ca = src0[0], cb = src0[1], cc = src0[2];
 
   for (int base = 0; base < n; base += kSeg) {
+    {   // Longest-remaining-first among the waves that share a SIMD: with equal priorities the short
+        // lists finish early and the long ones are left to run alone at one instruction per ~4.4
+        // cycles; with the long lists served first the SIMD stays shared until the end
+        // (88 -> 77 us on SYN-C; steps of 64 ... 512 splats measured, profiles/r02_forward_blend_tuning.txt).
+      const int rem = n - base;
+      if (rem > 3 * kFwdPrioStep) __builtin_amdgcn_s_setprio(3);
+      else if (rem > 2 * kFwdPrioStep) __builtin_amdgcn_s_setprio(2);
+      else if (rem > kFwdPrioStep) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
+    MGS_MARK(3);
     // issue the loads of the NEXT segment before touching this one
     const unsigned int nid = id_n1;
     const float4* src1 = reinterpret_cast<const float4*>(P.rec + nid);
     const float4 na = src1[0], nb4 = src1[1], nc = src1[2];
     id_n1 = fwd_load_id(P, start, n, base + 2 * kSeg + lane);
 
-#if defined(MGS_ABL) && MGS_ABL == 7
-    if (false) {
-#else
     if (base > 0 && base % kItem == 0) {   // checkpoint: state in front of this backward item
-#endif
       const int sg = seg0 + base / kItem;
       if (sg < P.max_segs) {
         float* ck = P.ckpt + (size_t)sg * (5 * 256) + ptile;
-        ck[0] = T; ck[256] = C01.x; ck[512] = C01.y; ck[768] = C2D.x; ck[1024] = C2D.y;
+        ck[0] = fabsf(T); ck[256] = C01.x; ck[512] = C01.y; ck[768] = C2D.x; ck[1024] = C2D.y;
       }
     }
-#if defined(MGS_ABL) && MGS_ABL == 8
-    const bool reach = base + lane < n && fabsf(ca.x - bx0 - 3.5f) < 12.f && fabsf(ca.y - by0 - 3.5f) < 12.f;
-#else
     const bool reach = base + lane < n &&
                        box_reachable(ca.x, ca.y, cb.x, cb.y, cb.z, splat_qmax(ca.w), bx0, by0, bx1, by1);
-#endif
     unsigned long long m = __builtin_amdgcn_ballot_w64(reach);
+    MGS_STAMP_SEG(m);
+    MGS_MARK(0);
     int touched = 0;
     if (m != 0ull) {
       __syncthreads();   // single-wave workgroup: orders the LDS traffic, no hardware barrier
       if (reach) {
-        s_rec[3 * lane] = make_float4(ca.x, ca.y, -0.5f * kLog2e * cb.x, -kLog2e * cb.y);
-        s_rec[3 * lane + 1] = make_float4(-0.5f * kLog2e * cb.z, ca.w, cc.x, cc.y);
-        s_rec[3 * lane + 2] = make_float4(cc.z, ca.z, 0.f, 0.f);
+        // log2 of the Gaussian falloff at pixel offset (x, y) from the quadrant centre, with
+        // d0 = mean - centre and (A, B, C) = -log2(e) (conic.x / 2, conic.y, conic.z / 2):
+        //   A (d0x - x)^2 + B (d0x - x)(d0y - y) + C (d0y - y)^2
+        //     = a0 + x (a1 + A x + B y) + y (a2 + C y)
+        // five FMAs per pixel on per-lane constants (x, y); |x|, |y| <= 3.5 keeps the cancellation
+        // error of the expanded form at a few 1e-6 of the exponent wherever alpha matters.
+        const float A = -0.5f * kLog2e * cb.x, B = -kLog2e * cb.y, Cc = -0.5f * kLog2e * cb.z;
+        const float d0x = ca.x - qcx, d0y = ca.y - qcy;
+        const float a0 = d0x * (A * d0x + B * d0y) + Cc * d0y * d0y;
+        const float a1 = -(2.f * A * d0x + B * d0y), a2 = -(B * d0x + 2.f * Cc * d0y);
+        s_rec[3 * lane] = make_float4(a0, a1, a2, A);
+        s_rec[3 * lane + 1] = make_float4(B, Cc, ca.w, 0.f);           // (B, C, opacity, -)
+        s_rec[3 * lane + 2] = make_float4(cc.x, cc.y, cc.z, ca.z);     // (r, g), (b, depth): packed-FMA pairs
       }
       __syncthreads();
       // n_touched only counts contributions made while T(1-alpha) > 0.5: once no pixel of the
       // quadrant is that transparent any more the counting code is skipped (wave-uniform)
-      const bool count_touch = __builtin_amdgcn_ballot_w64(T > kTouchT && live != 0.f) != 0ull;
+      MGS_MARK(1);
+      const bool count_touch = __builtin_amdgcn_ballot_w64(T > kTouchT) != 0ull;
       // the walk is instantiated twice (with / without the counting code) so that the choice
       // costs one branch per segment instead of instructions in every visit
       auto walk = [&](auto touch_tag) {
         constexpr bool kTouch = decltype(touch_tag)::value;
-        auto visit = [&](int j, const float4 u, const float4 v, const float2 bd) {
+        auto visit = [&](int j, const float4 u, const float4 v, const float4 c) {
 #if defined(MGS_ABL) && MGS_ABL == 5
           T -= 1e-9f * u.x; return;
 #endif
-          const float dx = u.x - fpx, dy = u.y - fpy;
-          const float pw = dx * (u.z * dx + u.w * dy) + v.x * dy * dy;
-          const float araw = v.y * __builtin_amdgcn_exp2f(pw);
-          float a = fminf(kAlphaMax, araw);
-          a = ((pw <= 0.f && a >= kAlphaMin) ? a : 0.f) * live;
-          const float test_T = T - a * T;
-          // T >= kTStop is invariant, so test_T < kTStop implies a > 0: the pixel saturates
-          // here, this splat is NOT blended and nothing after it is.
+          const float t1 = __builtin_fmaf(v.x, yh, __builtin_fmaf(u.w, xh, u.y));
+          const float t2 = __builtin_fmaf(v.y, yh, u.z);
+          // the quadratic form is <= 0; the clamp only removes rounding excursions of the expanded
+          // form (the reference's "power > 0: skip" can fire on rounding alone, too)
+          const float pw = fminf(0.f, __builtin_fmaf(yh, t2, __builtin_fmaf(xh, t1, u.x)));
+          float a = fminf(kAlphaMax, v.z * __builtin_amdgcn_exp2f(pw));
+          a = a >= kAlphaMin ? a : 0.f;
+          const float test_T = __builtin_fmaf(-a, T, T);
+          // T >= kTStop is invariant on live pixels, so test_T < kTStop implies a > 0: the pixel
+          // saturates here, this splat is NOT blended and nothing after it is (dead pixels: T < 0).
           const bool stop = test_T < kTStop;
-          live = stop ? 0.f : live;
-          a = stop ? 0.f : a;
-          const float w = a * T;
+          const float w = stop ? 0.f : a * T;
           const v2f ww = {w, w};
-          const v2f rg = {v.z, v.w}, bdv = {bd.x, bd.y};
+          const v2f rg = {c.x, c.y}, bdv = {c.z, c.w};
           C01 = __builtin_elementwise_fma(rg, ww, C01);
           C2D = __builtin_elementwise_fma(bdv, ww, C2D);
-          T = stop ? T : test_T;
-          last = a > 0.f ? (base + j + 1) : last;
+          T = stop ? -fabsf(T) : test_T;
+          const bool contrib = w > 0.f;
+          last = contrib ? (base + j + 1) : last;
           if constexpr (kTouch) {
-            const unsigned long long tm = __builtin_amdgcn_ballot_w64(a > 0.f && test_T > kTouchT);
-            if (tm != 0ull) touched += lane == j ? __popcll(tm) : 0;
+            // n_touched: contributions made while T (1 - alpha) > 0.5; lane j owns splat j's count
+            const unsigned long long tm = __builtin_amdgcn_ballot_w64(contrib) & __builtin_amdgcn_fcmpf(test_T, kTouchT, 2 /* OGT */);
+            const int cnt = __popcll(tm);
+            int tv = touched;
+            asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(tv) : "s"(cnt), "s"(j) : "m0");
+            touched = tv;
           }
         };
         // two-way unrolled walk over the set bits of m: splat j in (u0, v0, w0), the next one
         // is prefetched into (u1, v1, w1) and vice versa, so no registers are rotated
         int j0 = __builtin_ctzll(m);
-        float4 u0 = s_rec[3 * j0], v0 = s_rec[3 * j0 + 1];
-        float2 w0 = *reinterpret_cast<const float2*>(&s_rec[3 * j0 + 2]);
+        float4 u0 = s_rec[3 * j0], v0 = s_rec[3 * j0 + 1], w0 = s_rec[3 * j0 + 2];
         while (true) {
           mask_clear_bit(m, j0);
           const int j1 = __builtin_ctzll(m) & 63;       // m == 0: harmless read of slot 63
-          const float4 u1 = s_rec[3 * j1], v1 = s_rec[3 * j1 + 1];
-          const float2 w1 = *reinterpret_cast<const float2*>(&s_rec[3 * j1 + 2]);
+          const float4 u1 = s_rec[3 * j1], v1 = s_rec[3 * j1 + 1], w1 = s_rec[3 * j1 + 2];
           __builtin_amdgcn_sched_barrier(0);           // keep the prefetch above the arithmetic
           visit(j0, u0, v0, w0);
           if (m == 0ull) break;
           mask_clear_bit(m, j1);
           j0 = __builtin_ctzll(m) & 63;
-          u0 = s_rec[3 * j0]; v0 = s_rec[3 * j0 + 1];
-          w0 = *reinterpret_cast<const float2*>(&s_rec[3 * j0 + 2]);
+          u0 = s_rec[3 * j0]; v0 = s_rec[3 * j0 + 1]; w0 = s_rec[3 * j0 + 2];
           __builtin_amdgcn_sched_barrier(0);
           visit(j1, u1, v1, w1);
           if (m == 0ull) break;
@@ -798,15 +869,15 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
       };
       if (count_touch) walk(std::true_type{});
       else walk(std::false_type{});
+      MGS_MARK(2);
     }
-#if !(defined(MGS_ABL) && MGS_ABL == 6)
     if (touched > 0) atomicAdd(&P.n_touched[cid], touched);
-#endif
-    if (__builtin_amdgcn_ballot_w64(live != 0.f) == 0ull) break;   // quadrant saturated
+    if (__builtin_amdgcn_ballot_w64(T > 0.f) == 0ull) break;   // quadrant saturated
     cid = nid; ca = na; cb = nb4; cc = nc;
   }
   {   // state for the backward, quadrant-major (coalesced); lanes outside the image hold last = 0
     const size_t TQ = (size_t)256 * P.T, qi = (size_t)tile * 256 + ptile;
+    T = fabsf(T);
     P.final_T[qi] = T;
     P.n_contrib[qi] = last;
     P.final_C[qi] = C01.x; P.final_C[TQ + qi] = C01.y;

@@ -37,6 +37,9 @@ t0 = a[:, 0].min()
 start = (a[:, 0] - t0) / 100.0   # us (100 MHz)
 end = (a[:, 1] - t0) / 100.0
 dur = end - start
+nseg = (a[:, 2] >> 24) & 0xFFFF
+nvisit = (a[:, 2] >> 40) & 0xFFFFFF
+a[:, 2] = a[:, 2] & 0xFFFFFF
 clk = a[:, 2] / np.maximum(1, (a[:, 1] - a[:, 0])) * 100.0  # MHz
 hw = a[:, 3] & 0xffffffff
 xcc = a[:, 3] >> 32
@@ -84,3 +87,27 @@ print("wave dur percentiles", np.percentile(dur, [1, 10, 50, 90, 99, 100]).round
 # occupancy over time
 ts = np.linspace(0, end.max(), 12)
 print("resident waves at t:", [(round(float(t),1), int(((start <= t) & (end > t)).sum())) for t in ts])
+# per-wave instruction-time proxy: cycles (a[:,2]) and which tiles the slowest waves belong to
+cyc = a[:, 2]
+order = np.argsort(-dur)[:24]
+print("slowest waves (wg, tile, quad, dur us, Mcycles):", [(int(i), int(i) // 4, int(i) % 4, round(float(dur[i]), 1), round(float(cyc[i]) / 1e6, 3)) for i in order])
+print("sum of wave durations us %.0f  (= %.1f us if spread over 1024 SIMDs x 1)" % (dur.sum(), dur.sum() / 1024))
+print("dur histogram (10 us bins)", np.histogram(dur, bins=np.arange(0, 110, 10))[0])
+
+print("segments per wave: mean %.1f max %d ; visits per wave: mean %.0f max %d" % (nseg.mean(), nseg.max(), nvisit.mean(), nvisit.max()))
+print("slowest waves (nseg, nvisit):", [(int(nseg[i]), int(nvisit[i])) for i in order])
+A = np.stack([np.ones(T), nseg, nvisit], 1).astype(np.float64)
+coef, *_ = np.linalg.lstsq(A, dur, rcond=None)
+print("fit dur us = %.2f + %.3f * nseg + %.4f * nvisit ; residual std %.2f" % (coef[0], coef[1], coef[2], (A @ coef - dur).std()))
+work = A @ np.array([0.0, coef[1], coef[2]])
+wsum = np.array([work[skey == k].sum() for k in us])
+print("per-SIMD modelled work: mean %.1f max %.1f min %.1f ; corr(work sum, last end) %.2f" % (wsum.mean(), wsum.max(), wsum.min(), np.corrcoef(wsum, lastend)[0, 1]))
+wmax = np.array([work[skey == k].max() for k in us])
+print("per-SIMD longest-wave work: mean %.1f max %.1f ; corr(longest, last end) %.2f" % (wmax.mean(), wmax.max(), np.corrcoef(wmax, lastend)[0, 1]))
+
+pb = (C.c_longlong * (4 * T))()
+if hasattr(cabi.lib(), "mgs_debug_read_phases"):
+    cabi.lib().mgs_debug_read_phases(pb, 4 * T)
+    ph = np.array(pb[:], dtype=np.int64).reshape(T, 4) / (clk.mean())   # us
+    print("phase us per wave (mean): wait+reach %.1f  stage %.1f  walk %.1f  loop/ckpt/prefetch-issue %.1f ; per segment: %s" % (
+        ph[:, 0].mean(), ph[:, 1].mean(), ph[:, 2].mean(), ph[:, 3].mean(), (ph.sum(0) / nseg.sum()).round(2)))
