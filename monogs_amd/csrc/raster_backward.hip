@@ -13,6 +13,7 @@
 // Replaces rasterize_gaussians_backward of the reference's CUDA extension (its
 // autograd.Function is invoked through gaussian_renderer/__init__.py:151-168; gradient
 // sinks: gaussian_model.py:252-285,693-697, slam_frontend.py:365-378,606-611).
+#include <cstdlib>
 #include "launch.h"
 #include "raster_kernels.h"
 #include "wave_reduce.h"
@@ -56,8 +57,8 @@ __device__ __forceinline__ int pair_slot_base(const KP& P, int idx) {
 }
 
 // ---------------------------------------------------------------------------------
-// Blend backward, item-parallel.  One wave per work item = kItemSegs consecutive kSeg-splat
-// segments of one tile, FOUR pixels per lane, one in each 8x8 quadrant of the tile.  The lane that stages a splat
+// Blend backward, item-parallel.  One wave per work item = kItem consecutive splats of one tile's
+// list, FOUR pixels per lane, one in each 8x8 quadrant of the tile.  The lane that stages a splat
 // also evaluates the culling bound on the four quadrant boxes; the wave then visits, per
 // splat, only the quadrants that can be reached (wave-uniform scalar bit tests on ballot masks).
 // The quadrant body is written on float2 operands so that it maps onto v_pk_{add,mul,fma}_f32
@@ -88,23 +89,78 @@ constexpr float kLog2eB = 1.4426950408889634f;
 // POSE (plain mode only): pose-only backward (tracking: every per-Gaussian gradient pointer is
 // NULL).  dL/dtau needs the mean / conic / depth sums only, so the colour and opacity sums are
 // not formed and six values instead of ten are reduced per splat.
+#ifdef MGS_STAMP   // diagnostic build only (profiles/stamp_backward.py): per-item start/end stamps and phase times
+__device__ long long g_bstamps[4 * 65536];
+__device__ long long g_bphase[4 * 65536];
+extern "C" int mgs_debug_read_bwd_stamps(long long* stamps, long long* phases, int n) {
+  const int rc = (int)hipMemcpyFromSymbol(stamps, HIP_SYMBOL(g_bstamps), sizeof(long long) * n);
+  return rc ? rc : (int)hipMemcpyFromSymbol(phases, HIP_SYMBOL(g_bphase), sizeof(long long) * n);
+}
+__device__ int* g_item_order = nullptr;     // diagnostic: dispatch order of the items (experiment)
+extern "C" int mgs_debug_set_item_order(int* dev_ptr) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_item_order), &dev_ptr, sizeof(int*));
+}
+struct BwdStamp {
+  long long t0, tl, ph[4] = {0, 0, 0, 0};
+  int nvisit = 0, nany = 0, item_id = -1, item_base = 0, nmiss = 0, nlanes = 0;
+  __device__ BwdStamp() : t0(__builtin_amdgcn_s_memrealtime()), tl(__builtin_amdgcn_s_memtime()) {}
+  __device__ void mark(int k) { const long long t = __builtin_amdgcn_s_memtime(); ph[k] += t - tl; tl = t; }
+  __device__ ~BwdStamp() {
+    if (threadIdx.x == 0 && blockIdx.x < 65536) {
+      g_bstamps[4 * blockIdx.x + 0] = t0;
+      g_bstamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+      g_bstamps[4 * blockIdx.x + 2] = ((long long)nany << 32) | nvisit;
+      g_bphase[4 * blockIdx.x + 0] = ((long long)nmiss << 32) | (unsigned int)nlanes;
+      g_bstamps[4 * blockIdx.x + 3] = ((long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32) |
+                                      __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+      for (int k = 1; k < 3; k++) g_bphase[4 * blockIdx.x + k] = ph[k];
+      g_bphase[4 * blockIdx.x + 3] = ((long long)item_base << 32) | (unsigned int)item_id;
+    }
+  }
+};
+#define MGS_BSTAMP BwdStamp bstamp_
+#define MGS_BMARK(k) bstamp_.mark(k)
+#define MGS_BCOUNT(v, a) (bstamp_.nvisit += (v), bstamp_.nany += (a))
+#else
+#define MGS_BSTAMP
+#define MGS_BMARK(k)
+#define MGS_BCOUNT(v, a)
+#endif
+
+#ifndef MGS_BWD_OCC
+#define MGS_BWD_OCC 6
+#endif
 template <bool SKETCH, bool JONLY = false, bool POSE = false>
-__global__ __launch_bounds__(64, SKETCH ? 4 : (POSE ? 5 : 6)) void k_blend_bwd(KP P, KB B) {
+__global__ __launch_bounds__(64, SKETCH ? 4 : (POSE ? 5 : MGS_BWD_OCC)) void k_blend_bwd(KP P, KB B) {
+  MGS_BSTAMP;
   static_assert(SKETCH || !JONLY, "JONLY is a sketch-mode variant");
   static_assert(!(SKETCH && POSE), "POSE is a plain-mode variant");
   static_assert(kSeg == 64, "one staged record per lane");
   __shared__ float4 s_r0[kSeg], s_r1[kSeg];
   __shared__ float2 s_r2[kSeg];             // 2560 B of LDS in all: 25 waves per CU
   __shared__ float4 s_coef[SKETCH ? kSeg : 1][9];   // per splat: 6 features x 6 tau components
+#ifdef MGS_STAMP
+  int item = xcd_remap<kBwdChunk>(blockIdx.x);
+  const int lane = threadIdx.x;
+  if (g_item_order) item = g_item_order[item];
+  if (item < 0 || item >= min(P.seg_offset[P.T], P.max_segs)) return;
+#else
   const int item = xcd_remap<kBwdChunk>(blockIdx.x), lane = threadIdx.x;
   if (item >= min(P.seg_offset[P.T], P.max_segs)) return;
+#endif
   // One 16-B record per item (written by the tile sort) instead of a chain of dependent loads:
   // tile, index of the item's first key, number of splats (<= kItem), position in the tile's list.
 #if defined(MGS_BPRIO)
   __builtin_amdgcn_s_setprio(MGS_BPRIO == 1 ? 3 : 0);
 #endif
+#ifdef MGS_STAMP
+  bstamp_.item_id = item;
+#endif
   const int4 sr = P.seg_rec[item];
   const int tile = sr.x, k0 = sr.y, nb = sr.z, base = sr.w;
+#ifdef MGS_STAMP
+  bstamp_.item_base = base;
+#endif
   if (nb <= 0) return;
 #if defined(MGS_ABL) && MGS_ABL == 10
   return;
@@ -142,46 +198,69 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : (POSE ? 5 : 6)) void k_blend_bwd(K
       if (tx * kTile + 8 * (q & 1) >= P.W || ty * kTile + 8 * (q >> 1) >= P.H) qlast[q] = 0;
   }
   const size_t TQ = (size_t)256 * P.T;
+  const int tile_last = max(max(qlast[0], qlast[1]), max(qlast[2], qlast[3]));
 #pragma unroll
   for (int q = 0; q < 4; q++) {
-    const int px = qx + 8 * (q & 1), py = qy + 8 * (q >> 1);
     g0[q] = g1[q] = g2[q] = gd[q] = 0.f;
     last[q] = 0;
     T[q] = 0.f;
     gS[q] = 0.f;
-    if (qlast[q] <= base) continue;                   // wave-uniform: quadrant done before this item
-    const size_t qi = (size_t)tile * 256 + 64 * q + lane;     // quadrant-major: coalesced
-    float c0 = 0.f, c1 = 0.f, c2 = 0.f, cd = 0.f;
-    T[q] = 1.f;
-    last[q] = P.n_contrib[qi];
-    if (px < P.W && py < P.H) {
-      const size_t pix = (size_t)py * P.W + px;
-      g0[q] = B.grad_color[pix]; g1[q] = B.grad_color[HW + pix]; g2[q] = B.grad_color[2 * HW + pix];
-      if (B.grad_depth) gd[q] = B.grad_depth[pix];
-    }
-    {
-      const float tf = P.final_T[qi];
-      c0 = P.final_C[qi] + tf * bg0; c1 = P.final_C[TQ + qi] + tf * bg1;
-      c2 = P.final_C[2 * TQ + qi] + tf * bg2;
-      cd = P.final_C[3 * TQ + qi];
-    }
-    if (ck) {
-      const int p = 64 * q + lane;
-      T[q] = ck[p]; c0 -= ck[256 + p]; c1 -= ck[512 + p]; c2 -= ck[768 + p]; cd -= ck[1024 + p];
-    }
-    gS[q] = g0[q] * c0 + g1[q] * c1 + g2[q] * c2 + gd[q] * cd;
-    // a pixel whose list ended in front of this item contributes nothing here, and the
-    // forward stops checkpointing a quadrant once all its pixels are saturated: never let
-    // that (unwritten) state into the arithmetic
-    if (last[q] <= base) { T[q] = 0.f; gS[q] = 0.f; }
   }
-  const int tile_last = max(max(qlast[0], qlast[1]), max(qlast[2], qlast[3]));
+  if (tile_last > base) {      // wave-uniform; an item behind the tile's last contribution loads nothing
+    // All loads of the four quadrants are issued back to back, branch-free (addresses of pixels
+    // outside the image are clamped, quadrants that are already saturated are loaded anyway and
+    // masked below), and only then consumed: one memory round trip for the item's per-pixel state.
+    // (With a branch per quadrant the compiler drained the loads quadrant by quadrant: eight
+    // round trips in a row at the head of every item.)
+    int ln[4];
+    float tf[4], f0[4], f1[4], f2[4], f3[4];
+    bool in_img[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int px = qx + 8 * (q & 1), py = qy + 8 * (q >> 1);
+      in_img[q] = px < P.W && py < P.H;
+      const size_t pix = (size_t)min(py, P.H - 1) * P.W + min(px, P.W - 1);
+      const size_t qi = (size_t)tile * 256 + 64 * q + lane;     // quadrant-major: coalesced
+      ln[q] = P.n_contrib[qi];
+      g0[q] = B.grad_color[pix]; g1[q] = B.grad_color[HW + pix]; g2[q] = B.grad_color[2 * HW + pix];
+      gd[q] = B.grad_depth ? B.grad_depth[pix] : 0.f;
+      tf[q] = P.final_T[qi];
+      f0[q] = P.final_C[qi]; f1[q] = P.final_C[TQ + qi]; f2[q] = P.final_C[2 * TQ + qi]; f3[q] = P.final_C[3 * TQ + qi];
+    }
+    float kT[4] = {1.f, 1.f, 1.f, 1.f}, k0[4] = {0.f, 0.f, 0.f, 0.f}, k1[4] = {0.f, 0.f, 0.f, 0.f},
+          k2[4] = {0.f, 0.f, 0.f, 0.f}, k3[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ck) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int p = 64 * q + lane;
+        kT[q] = ck[p]; k0[q] = ck[256 + p]; k1[q] = ck[512 + p]; k2[q] = ck[768 + p]; k3[q] = ck[1024 + p];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (!in_img[q]) { g0[q] = 0.f; g1[q] = 0.f; g2[q] = 0.f; gd[q] = 0.f; }
+      const float c0 = f0[q] + tf[q] * bg0 - k0[q], c1 = f1[q] + tf[q] * bg1 - k1[q];
+      const float c2 = f2[q] + tf[q] * bg2 - k2[q], cd = f3[q] - k3[q];
+      const float gs = g0[q] * c0 + g1[q] * c1 + g2[q] * c2 + gd[q] * cd;
+      // a pixel whose list ended in front of this item contributes nothing here (and the forward
+      // stops checkpointing a quadrant once all its pixels are saturated: never let that
+      // unwritten state into the arithmetic); the same for a quadrant that is done as a whole
+      const bool on = qlast[q] > base && ln[q] > base;
+      last[q] = qlast[q] > base ? ln[q] : 0;
+      T[q] = on ? kT[q] : 0.f;
+      gS[q] = on ? gs : 0.f;
+      if (qlast[q] <= base) { g0[q] = 0.f; g1[q] = 0.f; g2[q] = 0.f; gd[q] = 0.f; }
+    }
+  }
+
 #if defined(MGS_ABL) && MGS_ABL == 11
   if (T[0] + T[1] + T[2] + T[3] + gS[0] + gS[1] + gS[2] + gS[3] + g0[0] + g0[1] + g0[2] + g0[3] == 123.456f && lo_next == 77u)
     B.pair_grad[lane].x = (float)(last[0] + last[1] + last[2] + last[3] + tile_last);
   return;
 #endif
 
+  MGS_BMARK(0);
   // sketch mode: per-pixel pose-Jacobian rows of this item, as pairs (tau 0,1) (2,3) (4,5)
   v2f J2[SKETCH ? 4 : 1][3];
 #pragma unroll
@@ -232,6 +311,10 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : (POSE ? 5 : 6)) void k_blend_bwd(K
       const float ar = v.y * __builtin_amdgcn_exp2f(pw);
       const float al = fminf(kAlphaMax, ar);
       const bool k = idx < last[q] && pw <= 0.f && al >= kAlphaMin;
+#ifdef MGS_STAMP
+      if (__ballot(k) == 0ull) bstamp_.nmiss++;
+      bstamp_.nlanes += __popcll(__ballot(k));
+#endif
       if (__ballot(k) == 0ull) continue;              // wave-uniform
       any = true;
       const float ae = k ? al : 0.f;
@@ -318,8 +401,8 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : (POSE ? 5 : 6)) void k_blend_bwd(K
       }
       if (!dead) {
         const float4* src = reinterpret_cast<const float4*>(P.rec + id);
-        const float4 qa = src[0], qb = src[1];
-        const float4 q2 = src[2];
+        const float4 qa = src[0];     // 16 + 12 + 12 B: no dead components (see k_blend_fwd)
+        const float3 qb = *reinterpret_cast<const float3*>(src + 1), q2 = *reinterpret_cast<const float3*>(src + 2);
         s_r0[lane] = make_float4(qa.x, qa.y, -0.5f * kLog2eB * qb.x, -kLog2eB * qb.y);
         s_r1[lane] = make_float4(-0.5f * kLog2eB * qb.z, qa.w, q2.x, q2.y);   // (C', opacity, r, g)
         s_r2[lane] = make_float2(q2.z, qa.z);                                  // (b, depth)
@@ -351,6 +434,8 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : (POSE ? 5 : 6)) void k_blend_bwd(K
       // unrolled with the NEXT splat's record prefetched from LDS above the arithmetic of the
       // current one, so that no LDS latency sits between two splats and no registers rotate.
       unsigned long long todo = mq[0] | mq[1] | mq[2] | mq[3];
+      MGS_BMARK(1);
+      MGS_BCOUNT(__popcll(mq[0]) + __popcll(mq[1]) + __popcll(mq[2]) + __popcll(mq[3]), __popcll(todo));
 #if defined(MGS_BPRIO)
       __builtin_amdgcn_s_setprio(MGS_BPRIO == 1 ? 0 : 3);
 #endif
@@ -379,6 +464,7 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : (POSE ? 5 : 6)) void k_blend_bwd(K
         }
       }
     }
+    MGS_BMARK(2);
     // splats of the segment that no pixel reached: zero record
 #if defined(MGS_ABL) && MGS_ABL == 12
     if (slot == 0x7fffffff)
@@ -740,7 +826,12 @@ int launch_backward(const KP& P, const KB& B, hipStream_t st, bool skip_tau_redu
     if (B.sketch_only) return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
   } else {
     if (B.g_means3D || B.map.on)
+#ifdef MGS_STAMP    // diagnostic: MGS_BWD_LDS_PAD bytes of dynamic LDS per item limit the items resident on a CU
+      launch_smem("blend_bwd", k_blend_bwd<false>, dim3(grid_pad(P.max_segs, kBwdChunk)), dim3(64),
+                  getenv("MGS_BWD_LDS_PAD") ? (size_t)atoi(getenv("MGS_BWD_LDS_PAD")) : 0, st, P, B);
+#else
       launch("blend_bwd", k_blend_bwd<false>, dim3(grid_pad(P.max_segs, kBwdChunk)), dim3(64), st, P, B);
+#endif
     else   // pose-only (tracking)
       launch("blend_bwd", k_blend_bwd<false, false, true>, dim3(grid_pad(P.max_segs, kBwdChunk)), dim3(64), st, P, B);
   }

@@ -757,8 +757,29 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
   unsigned int id_n1 = fwd_load_id(P, start, n, kSeg + lane);
   unsigned int cid = fwd_load_id(P, start, n, lane);
   const float4* src0 = reinterpret_cast<const float4*>(P.rec + cid);
-  float4 ca = src0[0], cb = src0[1], cc = src0[2];
+  // 16 + 12 + 12 bytes: the fourth dwords of the conic and colour rows are not used here, and a
+  // dead component of a wide load is a free register to the allocator - anything it parks there
+  // has to wait for the load to land (it cost one memory round trip per segment).
+  float4 ca = src0[0];
+  float3 cb = *reinterpret_cast<const float3*>(src0 + 1), cc = *reinterpret_cast<const float3*>(src0 + 2);
 
+  int touched_prev = 0;
+  unsigned int cid_prev = 0u;
+  // kItem < kSeg: a backward item starts in the MIDDLE of a segment, too.  The state in front of
+  // it is parked in registers and stored with the next iteration's memory traffic (a store issued
+  // in the middle of the walk would be the youngest operation at the loop's s_waitcnt).
+  constexpr int kParts = kItem < kSeg ? kSeg / kItem : 1;
+  static_assert(kParts <= 2 && (kItem >= kSeg || kSeg % kItem == 0), "at most one checkpoint inside a segment");
+  int sg_mid = -1;
+  float mid_T = 0.f;
+  v2f mid_01 = {0.f, 0.f}, mid_2D = {0.f, 0.f};
+  auto flush_mid = [&]() {
+    if (sg_mid >= 0 && sg_mid < P.max_segs) {
+      float* ck = P.ckpt + (size_t)sg_mid * (5 * 256) + ptile;
+      ck[0] = mid_T; ck[256] = mid_01.x; ck[512] = mid_01.y; ck[768] = mid_2D.x; ck[1024] = mid_2D.y;
+    }
+    sg_mid = -1;
+  };
   for (int base = 0; base < n; base += kSeg) {
     {   // Longest-remaining-first among the waves that share a SIMD: with equal priorities the short
         // lists finish early and the long ones are left to run alone at one instruction per ~4.4
@@ -771,12 +792,22 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
       else __builtin_amdgcn_s_setprio(0);
     }
     MGS_MARK(3);
-    // issue the loads of the NEXT segment before touching this one
-    const unsigned int nid = id_n1;
-    const float4* src1 = reinterpret_cast<const float4*>(P.rec + nid);
-    const float4 na = src1[0], nb4 = src1[1], nc = src1[2];
-    id_n1 = fwd_load_id(P, start, n, base + 2 * kSeg + lane);
-
+    // everything in flight was issued a whole walk ago: drain it here, on every path, so that the
+    // compiler has no reason to wait (with a count sized for its shortest path) further down
+    asm volatile("" :: "v"(ca.x), "v"(cb.x), "v"(cc.x), "v"(id_n1));
+    // The reach test comes FIRST and all memory traffic of the iteration is issued behind it: the
+    // wait in front of the test then only covers operations issued a whole walk earlier.  (s_waitcnt
+    // counts in order and the compiler sizes it for the path with the fewest later operations; with
+    // the next segment's loads, the checkpoint stores or the n_touched atomic in front of the test it
+    // waited for those, one memory round trip per segment.)
+    const bool reach = base + lane < n &&
+                       box_reachable(ca.x, ca.y, cb.x, cb.y, cb.z, splat_qmax(ca.w), bx0, by0, bx1, by1);
+    unsigned long long m = __builtin_amdgcn_ballot_w64(reach);
+    MGS_STAMP_SEG(m);
+    MGS_MARK(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (touched_prev > 0) atomicAdd(&P.n_touched[cid_prev], touched_prev);   // previous segment's counts
+    if constexpr (kParts > 1) flush_mid();
     if (base > 0 && base % kItem == 0) {   // checkpoint: state in front of this backward item
       const int sg = seg0 + base / kItem;
       if (sg < P.max_segs) {
@@ -784,12 +815,15 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
         ck[0] = fabsf(T); ck[256] = C01.x; ck[512] = C01.y; ck[768] = C2D.x; ck[1024] = C2D.y;
       }
     }
-    const bool reach = base + lane < n &&
-                       box_reachable(ca.x, ca.y, cb.x, cb.y, cb.z, splat_qmax(ca.w), bx0, by0, bx1, by1);
-    unsigned long long m = __builtin_amdgcn_ballot_w64(reach);
-    MGS_STAMP_SEG(m);
-    MGS_MARK(0);
+    // loads of the NEXT segment (records) and of the one after it (ids)
+    const unsigned int nid = id_n1;
+    const float4* src1 = reinterpret_cast<const float4*>(P.rec + nid);
+    const float4 na = src1[0];
+    const float3 nb4 = *reinterpret_cast<const float3*>(src1 + 1), nc = *reinterpret_cast<const float3*>(src1 + 2);
+    id_n1 = fwd_load_id(P, start, n, base + 2 * kSeg + lane);
+    __builtin_amdgcn_sched_barrier(0);
     int touched = 0;
+    bool count_touch = false;
     if (m != 0ull) {
       __syncthreads();   // single-wave workgroup: orders the LDS traffic, no hardware barrier
       if (reach) {
@@ -811,10 +845,12 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
       // n_touched only counts contributions made while T(1-alpha) > 0.5: once no pixel of the
       // quadrant is that transparent any more the counting code is skipped (wave-uniform)
       MGS_MARK(1);
-      const bool count_touch = __builtin_amdgcn_ballot_w64(T > kTouchT) != 0ull;
+      count_touch = __builtin_amdgcn_ballot_w64(T > kTouchT) != 0ull;
+    }
+    {
       // the walk is instantiated twice (with / without the counting code) so that the choice
       // costs one branch per segment instead of instructions in every visit
-      auto walk = [&](auto touch_tag) {
+      auto walk = [&](auto touch_tag, unsigned long long m) {
         constexpr bool kTouch = decltype(touch_tag)::value;
         auto visit = [&](int j, const float4 u, const float4 v, const float4 c) {
 #if defined(MGS_ABL) && MGS_ABL == 5
@@ -843,8 +879,11 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
             // n_touched: contributions made while T (1 - alpha) > 0.5; lane j owns splat j's count
             const unsigned long long tm = __builtin_amdgcn_ballot_w64(contrib) & __builtin_amdgcn_fcmpf(test_T, kTouchT, 2 /* OGT */);
             const int cnt = __popcll(tm);
-            int tv = touched;
-            asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(tv) : "s"(cnt), "s"(j) : "m0");
+            // v_writelane with two SGPR sources needs the lane select in M0 (one constant-bus read);
+            // M0 is a reserved register, so it is handed back as it was found
+            int tv = touched, m0_saved;
+            asm("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                : "+v"(tv), "=&s"(m0_saved) : "s"(cnt), "s"(j));
             touched = tv;
           }
         };
@@ -867,14 +906,29 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
           if (m == 0ull) break;
         }
       };
-      if (count_touch) walk(std::true_type{});
-      else walk(std::false_type{});
+      auto walk_part = [&](unsigned long long mm) {      // mm != 0 implies m != 0: the records are staged
+        if (mm == 0ull) return;
+        if (count_touch) walk(std::true_type{}, mm);
+        else walk(std::false_type{}, mm);
+      };
+      if constexpr (kParts > 1) {
+        walk_part(m & ((1ull << kItem) - 1ull));
+        if (base + kItem < n) {
+          mid_T = fabsf(T); mid_01 = C01; mid_2D = C2D;
+          sg_mid = seg0 + (base + kItem) / kItem;
+        }
+        walk_part(m & ~((1ull << kItem) - 1ull));
+      } else {
+        walk_part(m);
+      }
       MGS_MARK(2);
     }
-    if (touched > 0) atomicAdd(&P.n_touched[cid], touched);
+    touched_prev = touched; cid_prev = cid;
     if (__builtin_amdgcn_ballot_w64(T > 0.f) == 0ull) break;   // quadrant saturated
     cid = nid; ca = na; cb = nb4; cc = nc;
   }
+  if (touched_prev > 0) atomicAdd(&P.n_touched[cid_prev], touched_prev);
+  if constexpr (kParts > 1) flush_mid();
   {   // state for the backward, quadrant-major (coalesced); lanes outside the image hold last = 0
     const size_t TQ = (size_t)256 * P.T, qi = (size_t)tile * 256 + ptile;
     T = fabsf(T);

@@ -113,14 +113,16 @@ constexpr int kPreBlock = 256;
 constexpr int kPackBits = 12;
 constexpr int kPackMaxN = 1 << 20;
 constexpr int kSeg = 64;            // splats staged at a time by the blend kernels (one record per lane)
-// A backward work item is kItemSegs consecutive segments of one tile (the per-pixel state is loaded
+// A backward work item is kItem consecutive splats of one tile's list (the per-pixel state is loaded
 // once per item and carried across its segments in registers; the forward checkpoints the blend
 // state in front of every item).  Measured on SYN-C (profiles/r02_item_size_experiment.txt):
 // 1 segment per item 136 us, 2: 160 us, 4: 192 us - larger items cut the per-item loads but leave
 // fewer items (3.7k at 4) than the chip has wave slots (~5.6k), and the kernel then runs at the
 // latency of one long item instead of at the chip's throughput.  So: 1.
-constexpr int kItemSegs = 1;
-constexpr int kItem = kSeg * kItemSegs;
+// HALF a segment per item is faster still (126 -> ~112 us): the kernel's duration is set by its last
+// round of items, which run two or three to a SIMD at the latency of a lone wave; shorter items make
+// that round shorter, at the price of a second per-pixel state load and checkpoint per segment.
+constexpr int kItem = 32;
 constexpr int kBinBlocks = 512;    // workgroups of the LDS-privatised binning passes
 constexpr int kBinThreads = 1024;
 constexpr int kBinMaxTilesLds = 12288;   // T above this falls back to global atomics
