@@ -53,7 +53,7 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
 // laid out in index order, so the gather pass streams.  The offsets come out of the forward
 // binning (block-local scan + scan of the block totals), no scan is launched here.
 __device__ __forceinline__ int pair_slot_base(const KP& P, int idx) {
-  return P.block_prefix[idx / P.counters[2]] + P.pair_off[idx];
+  return P.block_prefix[idx / P.per_block] + P.pair_off[idx];
 }
 
 // ---------------------------------------------------------------------------------
@@ -593,6 +593,7 @@ __global__ __launch_bounds__(256) void k_sketch_bucket(KP P, KB B) {
 // accumulate into the per-iteration gradient buffer of the raw parameters, add the isotropic
 // regulariser's gradient (slam_backend.py:244-246) and this view's densification statistics
 // (gaussian_model.py:693-697, slam_backend.py:292-299) and occ-aware visibility (:251-255).
+// (no waves-per-SIMD bound: with an explicit 4 the same kernel ran 26 -> 35 us, with 5 or 6 it spills)
 template <bool MAP>
 __global__ __launch_bounds__(kPreBlock) void k_preprocess_bwd(KP P, KB B) {
   __shared__ float s_tau[kPreBlock / 64][6];
@@ -600,19 +601,41 @@ __global__ __launch_bounds__(kPreBlock) void k_preprocess_bwd(KP P, KB B) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (idx < P.N) {
-    const float4 r1 = reinterpret_cast<const float4*>(P.rec + idx)[1];
-    const float4 r2 = reinterpret_cast<const float4*>(P.rec + idx)[2];
+    // Every load that depends on idx alone is issued here, ahead of any use and outside the
+    // "visible" branch: one memory round trip, then one more for the pair records (it was five in a
+    // row: record -> slot offsets -> pair records -> scales / rotation -> model parameters).
+    const float4* recp = reinterpret_cast<const float4*>(P.rec + idx);
+    const float4 r0 = recp[0], r1 = recp[1], r2 = recp[2];
+    const float p[3] = {P.means[3 * idx], P.means[3 * idx + 1], P.means[3 * idx + 2]};
+    const int pair_cnt = P.pair_count[idx], pair_o = P.pair_off[idx];
+    // per_block is a multiple of kPreBlock: the binning block of this whole workgroup (scalar load)
+    const int pair_b = P.block_prefix[(blockIdx.x * kPreBlock) / P.per_block];
+    float sc[3] = {1.f, 1.f, 1.f}, c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float4 qq = make_float4(1.f, 0.f, 0.f, 0.f);
+    if (P.covp) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) c6[i] = P.covp[6 * (size_t)idx + i];
+    } else {
+      sc[0] = P.scales[3 * idx]; sc[1] = P.scales[3 * idx + 1]; sc[2] = P.scales[3 * idx + 2];
+      qq = reinterpret_cast<const float4*>(P.rots)[idx];
+    }
+    float map_o = 0.f;
+    float4 map_qr = make_float4(1.f, 0.f, 0.f, 0.f);
+    if constexpr (MAP) {
+      map_o = P.opac[idx];
+      map_qr = reinterpret_cast<const float4*>(B.map.raw_rot)[idx];
+    }
+    __builtin_amdgcn_sched_barrier(0);
     const int radius = __float_as_int(r1.w);
     const unsigned int flags = __float_as_uint(r2.w);
     float dmean[3] = {0.f, 0.f, 0.f}, dndc[2] = {0.f, 0.f}, dop = 0.f;
     float dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
     float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float grgb[3] = {0.f, 0.f, 0.f};
-    const float p[3] = {P.means[3 * idx], P.means[3 * idx + 1], P.means[3 * idx + 2]};
     if (radius > 0) {
       float a[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       // clamped to the capacity of the pair_grad buffer (see k_blend_bwd)
-      const int s0 = min(pair_slot_base(P, idx), P.cap), s1 = min(s0 + P.pair_count[idx], P.cap);
+      const int s0 = min(pair_b + pair_o, P.cap), s1 = min(s0 + pair_cnt, P.cap);
       // four slots in flight per trip (predicated loads, issued back to back): the loop is bound by
       // load latency, not by bytes - one slot per trip costs one round trip per pair of the Gaussian
       for (int s = s0; s < s1; s += 4) {
@@ -637,7 +660,6 @@ __global__ __launch_bounds__(kPreBlock) void k_preprocess_bwd(KP P, KB B) {
       // a[] = raw pixel sums (S1, Sx, Sy, Sxx, Sxy, Syy, Rr, Rg, Rb, Rd) over all tiles of
       // the Gaussian; the conic / opacity are per-Gaussian, so the linear map to screen-space
       // gradients is applied once here instead of once per pair
-      const float4 r0 = reinterpret_cast<const float4*>(P.rec + idx)[0];
       const float cA = r1.x, cB = r1.y, cC = r1.z;
       const float g_xy[2] = {-(cA * a[1] + cB * a[2]), -(cC * a[2] + cB * a[1])};
       const float g_con[3] = {-0.5f * a[3], -a[4], -0.5f * a[5]};
@@ -646,13 +668,8 @@ __global__ __launch_bounds__(kPreBlock) void k_preprocess_bwd(KP P, KB B) {
       load_camera_b(cam, P);
       GaussGrad gg;
       if (P.covp) {
-        float c6[6];
-#pragma unroll
-        for (int i = 0; i < 6; i++) c6[i] = P.covp[6 * (size_t)idx + i];
         project_gaussian_backward(cam, p, nullptr, nullptr, c6, g_xy, g_con, g_op, a[9], gg);
       } else {
-        const float sc[3] = {P.scales[3 * idx], P.scales[3 * idx + 1], P.scales[3 * idx + 2]};
-        const float4 qq = reinterpret_cast<const float4*>(P.rots)[idx];
         const float q[4] = {qq.x, qq.y, qq.z, qq.w};
         project_gaussian_backward(cam, p, sc, q, nullptr, g_xy, g_con, g_op, a[9], gg);
       }
@@ -691,11 +708,11 @@ __global__ __launch_bounds__(kPreBlock) void k_preprocess_bwd(KP P, KB B) {
 #pragma unroll
       for (int i = 0; i < 3; i++) put(&M.g_xyz[3 * (size_t)idx + i], dmean[i]);
       // opacity = sigmoid(logit)
-      const float o = P.opac[idx];
+      const float o = map_o;
       put(&M.g_opacity[idx], dop * o * (1.f - o));
       // scaling = exp(log scale) (+ regulariser: weight * mean_{N x 3} |s_k - mean_k s|)
       {
-        const float s0 = P.scales[3 * idx], s1 = P.scales[3 * idx + 1], s2 = P.scales[3 * idx + 2];
+        const float s0 = sc[0], s1 = sc[1], s2 = sc[2];
         float g0 = dscale[0] * s0, g1 = dscale[1] * s1, g2 = dscale[2] * s2;
         if (M.scale_dims == 3) {
           if (M.add_reg) {
@@ -716,7 +733,7 @@ __global__ __launch_bounds__(kPreBlock) void k_preprocess_bwd(KP P, KB B) {
       }
       // rotation = q / |q|:  dL/dq = (g - qn (qn . g)) / |q|
       {
-        const float4 qr = reinterpret_cast<const float4*>(M.raw_rot)[idx];
+        const float4 qr = map_qr;
         const float n2 = qr.x * qr.x + qr.y * qr.y + qr.z * qr.z + qr.w * qr.w;
         const float inv = 1.f / fmaxf(sqrtf(n2), 1e-12f);
         const float qn[4] = {qr.x * inv, qr.y * inv, qr.z * inv, qr.w * inv};

@@ -91,6 +91,8 @@ int fill_kp(const mgs_forward_args& a, bool need_bins, bool need_outputs, KP& P)
   P.max_segs = (int)L.max_segs;
   P.out_color = a.out_color; P.out_depth = a.out_depth; P.out_opacity = a.out_opacity;
   P.radii = a.radii; P.n_touched = a.n_touched; P.d_out = a.pair_count_out; P.d_max = a.pair_count_max;
+  if (P.T <= kBinMaxTilesLds) { int nblk; bin_grid(P.N, nblk, P.per_block); }
+  else P.per_block = 0x7fffffff;
   P.big_pass = a.big_tile_pass < 0 ? 0 : 1;
   P.clamp_up = 0;
   return MGS_OK;

@@ -212,7 +212,6 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_lds(KP P, int emit, int per
     for (int t = tid; t < P.T; t += kBinThreads) row[t] = s_tile[t];
     if (tid == 0) {
       P.scan_tmp[blockIdx.x] = carry;          // block total, scanned by k_tile_scan
-      if (blockIdx.x == 0) P.counters[2] = per_block;
     }
   }
 }
@@ -337,7 +336,6 @@ __device__ __forceinline__ void tile_scan_body(const KP& P, int nbin, int* s_sum
     __syncthreads();
   } else if (tid == 0) {   // fallback path: pair_off already holds the global scan
     P.block_prefix[0] = 0;
-    P.counters[2] = 0x7fffffff;
   }
   const int per = (P.T + 1023) / 1024;
   const int lo = tid * per, hi = min(lo + per, P.T);
@@ -977,9 +975,18 @@ static inline int bin_blocks(int N) {
   return b;
 }
 
+// Gaussians per workgroup are rounded up to a multiple of kPreBlock, so that idx / per is uniform
+// over a workgroup of the preprocess backward (its block_prefix entry is one scalar load).
+void bin_grid(int N, int& nblk, int& per) {
+  const int b = bin_blocks(N);
+  per = ((N + b - 1) / b + kPreBlock - 1) / kPreBlock * kPreBlock;
+  nblk = (N + per - 1) / per;
+}
+
 int launch_forward_project(const KP& P, hipStream_t st) {
   if (P.T <= kBinMaxTilesLds) {
-    const int nblk = bin_blocks(P.N), per = (P.N + nblk - 1) / nblk;
+    int nblk, per;
+    bin_grid(P.N, nblk, per);
     launch_smem("project_bin_count", k_bin_lds, dim3(nblk), dim3(kBinThreads), sizeof(int) * (size_t)P.T, st, P, 0, per, 1);
     launch("bin_colsum", k_bin_colsum, dim3((P.T + 63) / 64), dim3(64 * kColGroups), st, P, nblk);   // + tile scan
   } else {
@@ -998,7 +1005,8 @@ int launch_forward_blend(const KP& P, hipStream_t st) {
   // cursors restart at 0 on every call so a retry with a larger capacity is valid
   // (n_touched is zeroed by the emit pass of the LDS path)
   if (P.T <= kBinMaxTilesLds) {
-    const int nblk = bin_blocks(P.N), per = (P.N + nblk - 1) / nblk;
+    int nblk, per;
+    bin_grid(P.N, nblk, per);
     launch_smem("bin_emit", k_bin_lds, dim3(nblk), dim3(kBinThreads), sizeof(int) * (size_t)P.T, st, P, 1, per, 0);
   } else {
     if (hipMemsetAsync(P.tile_cursor, 0, sizeof(int) * (size_t)P.T, st) != hipSuccess ||

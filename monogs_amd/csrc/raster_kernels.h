@@ -49,6 +49,8 @@ struct KP {
   int *radii, *n_touched;
   int* d_out;              // optional extra destination of D (may be pinned host memory)
   int* d_max;              // optional sticky high-water mark of D (atomicMax)
+  int per_block;           // Gaussians per binning workgroup (a multiple of kPreBlock; 0x7fffffff on the
+                           // global-atomics fallback): block_prefix[idx / per_block] + pair_off[idx] = first slot
   int big_pass;            // 1: tiles of more than 1024 pairs are left to the second sort launch
   int clamp_up;            // backward: mgs_backward_args.clamp_gradient_mode
 };
@@ -126,6 +128,10 @@ constexpr int kItem = 32;
 constexpr int kBinBlocks = 512;    // workgroups of the LDS-privatised binning passes
 constexpr int kBinThreads = 1024;
 constexpr int kBinMaxTilesLds = 12288;   // T above this falls back to global atomics
+
+// Grid of the LDS-privatised binning passes (defined in raster_forward.hip): number of workgroups
+// and Gaussians per workgroup for N Gaussians.
+void bin_grid(int N, int& nblk, int& per);
 
 inline Layout make_layout(const mgs_raster_shape& s) {
   Layout L;
