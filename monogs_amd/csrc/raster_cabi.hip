@@ -81,7 +81,6 @@ int fill_kp(const mgs_forward_args& a, bool need_bins, bool need_outputs, KP& P)
   P.seg_offset = (int*)(g + L.seg_offset);
   P.n_contrib = (int*)(g + L.n_contrib);
   P.quad_last = (int*)(g + L.quad_last);
-  P.tile_order = (int*)(g + L.tile_order);
   P.counters = (int*)(g + L.counters);
   char* b = (char*)a.bins;
   P.keys = b ? (unsigned long long*)(b + L.keys) : nullptr;

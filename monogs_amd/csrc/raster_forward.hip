@@ -316,7 +316,6 @@ __global__ __launch_bounds__(256) void k_scan_write(KP P) {
 // ---------------------------------------------------------------------------------
 // Exclusive scans of the T tile counts (-> tile_offset, D) and of the per-tile segment
 // backward item counts ceil(n_t / kItem) (-> seg_offset) by one 1024-thread workgroup.
-constexpr int kOrderClasses = 128, kOrderStep = 32;
 __device__ __forceinline__ void tile_scan_body(const KP& P, int nbin, int* s_sum, int* s_seg) {
   __shared__ int s_tmax;
   const int tid = threadIdx.x;
@@ -380,36 +379,6 @@ __device__ __forceinline__ void tile_scan_body(const KP& P, int nbin, int* s_sum
     }
     P.counters[1] = s_seg[1023];
     if (P.d_max) atomicMax(P.d_max, s_sum[1023]);
-  }
-  // Launch order of the forward blend: tiles by decreasing list length (counting sort on
-  // n / kOrderStep, longest class first; the order inside a class is arbitrary and irrelevant).
-  // All 4T quadrant waves are resident at once and the dispatcher deals consecutive workgroups
-  // round-robin, so every SIMD gets one wave of each length class instead of a random draw.
-  __syncthreads();
-  int* s_hist = s_seg;
-  if (tid < kOrderClasses) s_hist[tid] = 0;
-  __syncthreads();
-  for (int i = lo; i < hi; i++) {
-    const int c = __hip_atomic_load(&P.tile_count[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    atomicAdd(&s_hist[kOrderClasses - 1 - min(kOrderClasses - 1, c / kOrderStep)], 1);
-  }
-  __syncthreads();
-  if (tid < 64) {    // exclusive scan of the class sizes by one wave (kOrderClasses = 2 x 64)
-    static_assert(kOrderClasses == 128, "two classes per lane");
-    const int a = s_hist[2 * tid], b = s_hist[2 * tid + 1];
-    int incl = a + b;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int t = __shfl_up(incl, off);
-      if (tid >= off) incl += t;
-    }
-    s_hist[2 * tid] = incl - a - b;
-    s_hist[2 * tid + 1] = incl - b;
-  }
-  __syncthreads();
-  for (int i = lo; i < hi; i++) {
-    const int c = __hip_atomic_load(&P.tile_count[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    P.tile_order[atomicAdd(&s_hist[kOrderClasses - 1 - min(kOrderClasses - 1, c / kOrderStep)], 1)] = i;
   }
 }
 
@@ -721,11 +690,7 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
   __shared__ float4 s_rec[kSeg * 3];
   const int item = xcd_remap<kFwdChunk>(blockIdx.x);
   if (item >= 4 * P.T) return;
-#if defined(MGS_NO_ORDER)
   const int tile = item >> 2, quad = item & 3, lane = threadIdx.x;
-#else
-  const int tile = P.tile_order[item >> 2], quad = item & 3, lane = threadIdx.x;
-#endif
   const int tx = tile % P.grid_x, ty = tile / P.grid_x;
   const int qx0 = tx * kTile + 8 * (quad & 1), qy0 = ty * kTile + 8 * (quad >> 1);
   if (qx0 >= P.W || qy0 >= P.H) return;                  // quadrant outside the image

@@ -36,7 +36,6 @@ struct KP {
   int* quad_last;          // [4 T] max of n_contrib over the quadrant: the list position behind which the
                            // quadrant is saturated (the backward skips it from there on)
   int* seg_offset;         // T+1: exclusive scan of ceil(n_t / kItem): first backward item of a tile
-  int* tile_order;         // T: tiles by decreasing list length (launch order of the forward blend)
   int* counters;
   // bins workspace
   unsigned long long* keys;
@@ -101,7 +100,7 @@ inline uint64_t align_up(uint64_t v) { return (v + kAlign - 1) / kAlign * kAlign
 
 struct Layout {
   uint64_t rec, pair_count, pair_off, block_prefix, scan_tmp, tile_count, tile_offset, tile_cursor, bin_table, final_T, final_C,
-      n_contrib, quad_last, seg_offset, tile_order, counters, geom_bytes;
+      n_contrib, quad_last, seg_offset, counters, geom_bytes;
   uint64_t keys, payload, seg_rec, ckpt, max_segs, bins_bytes;
   uint64_t pair_grad, tau_partial, bwd_bytes;
   uint64_t pix_jac, splat_jac, sketch_bytes;
@@ -157,7 +156,6 @@ inline Layout make_layout(const mgs_raster_shape& s) {
   L.n_contrib = o; o = align_up(o + T * 256 * 4);
   L.quad_last = o; o = align_up(o + T * 4 * 4);
   L.seg_offset = o; o = align_up(o + (T + 1) * 4);
-  L.tile_order = o; o = align_up(o + T * 4);
   L.counters = o; o = align_up(o + 16);
   L.geom_bytes = o;
   o = 0;
