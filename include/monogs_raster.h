@@ -63,8 +63,8 @@ typedef struct mgs_workspace_sizes {
   uint64_t off_records;      /* N x 48 B  mgs SplatRec                       */
   uint64_t off_pair_count;   /* N x int32 pairs emitted per Gaussian         */
   uint64_t off_tile_offset;  /* (T+1) x int32 exclusive scan of tile counts  */
-  uint64_t off_final_T;      /* W*H x float                                  */
-  uint64_t off_n_contrib;    /* W*H x int32                                  */
+  uint64_t off_final_T;      /* 256 T x float4 (T, C0, C1, C2), quadrant-major */
+  uint64_t off_n_contrib;    /* 256 T x (float depth, int32 n_contrib)       */
   uint64_t off_counters;     /* 4 x int32: [0] = total pairs D               */
   /* byte offsets inside `bins` */
   uint64_t off_keys;         /* capacity x uint64: depth_bits<<32 | gaussian id, sorted per tile */

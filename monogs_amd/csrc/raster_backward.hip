@@ -197,7 +197,6 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : (POSE ? 5 : MGS_BWD_OCC)) void k_b
     for (int q = 0; q < 4; q++)
       if (tx * kTile + 8 * (q & 1) >= P.W || ty * kTile + 8 * (q >> 1) >= P.H) qlast[q] = 0;
   }
-  const size_t TQ = (size_t)256 * P.T;
   const int tile_last = max(max(qlast[0], qlast[1]), max(qlast[2], qlast[3]));
 #pragma unroll
   for (int q = 0; q < 4; q++) {
@@ -212,8 +211,8 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : (POSE ? 5 : MGS_BWD_OCC)) void k_b
     // masked below), and only then consumed: one memory round trip for the item's per-pixel state.
     // (With a branch per quadrant the compiler drained the loads quadrant by quadrant: eight
     // round trips in a row at the head of every item.)
-    int ln[4];
-    float tf[4], f0[4], f1[4], f2[4], f3[4];
+    int2 dl[4];
+    float4 tc[4];
     bool in_img[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -221,34 +220,38 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : (POSE ? 5 : MGS_BWD_OCC)) void k_b
       in_img[q] = px < P.W && py < P.H;
       const size_t pix = (size_t)min(py, P.H - 1) * P.W + min(px, P.W - 1);
       const size_t qi = (size_t)tile * 256 + 64 * q + lane;     // quadrant-major: coalesced
-      ln[q] = P.n_contrib[qi];
+      dl[q] = P.final_DL[qi];
       g0[q] = B.grad_color[pix]; g1[q] = B.grad_color[HW + pix]; g2[q] = B.grad_color[2 * HW + pix];
       gd[q] = B.grad_depth ? B.grad_depth[pix] : 0.f;
-      tf[q] = P.final_T[qi];
-      f0[q] = P.final_C[qi]; f1[q] = P.final_C[TQ + qi]; f2[q] = P.final_C[2 * TQ + qi]; f3[q] = P.final_C[3 * TQ + qi];
+      tc[q] = P.final_TC[qi];
     }
-    float kT[4] = {1.f, 1.f, 1.f, 1.f}, k0[4] = {0.f, 0.f, 0.f, 0.f}, k1[4] = {0.f, 0.f, 0.f, 0.f},
-          k2[4] = {0.f, 0.f, 0.f, 0.f}, k3[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 k4[4];
+    float k3[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; q++) k4[q] = make_float4(1.f, 0.f, 0.f, 0.f);
     if (ck) {
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const int p = 64 * q + lane;
-        kT[q] = ck[p]; k0[q] = ck[256 + p]; k1[q] = ck[512 + p]; k2[q] = ck[768 + p]; k3[q] = ck[1024 + p];
+        k4[q] = reinterpret_cast<const float4*>(ck)[p];
+        k3[q] = ck[1024 + p];
       }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       if (!in_img[q]) { g0[q] = 0.f; g1[q] = 0.f; g2[q] = 0.f; gd[q] = 0.f; }
-      const float c0 = f0[q] + tf[q] * bg0 - k0[q], c1 = f1[q] + tf[q] * bg1 - k1[q];
-      const float c2 = f2[q] + tf[q] * bg2 - k2[q], cd = f3[q] - k3[q];
+      const float tf = tc[q].x;
+      const int ln_q = dl[q].y;
+      const float c0 = tc[q].y + tf * bg0 - k4[q].y, c1 = tc[q].z + tf * bg1 - k4[q].z;
+      const float c2 = tc[q].w + tf * bg2 - k4[q].w, cd = __int_as_float(dl[q].x) - k3[q];
       const float gs = g0[q] * c0 + g1[q] * c1 + g2[q] * c2 + gd[q] * cd;
       // a pixel whose list ended in front of this item contributes nothing here (and the forward
       // stops checkpointing a quadrant once all its pixels are saturated: never let that
       // unwritten state into the arithmetic); the same for a quadrant that is done as a whole
-      const bool on = qlast[q] > base && ln[q] > base;
-      last[q] = qlast[q] > base ? ln[q] : 0;
-      T[q] = on ? kT[q] : 0.f;
+      const bool on = qlast[q] > base && ln_q > base;
+      last[q] = qlast[q] > base ? ln_q : 0;
+      T[q] = on ? k4[q].x : 0.f;
       gS[q] = on ? gs : 0.f;
       if (qlast[q] <= base) { g0[q] = 0.f; g1[q] = 0.f; g2[q] = 0.f; gd[q] = 0.f; }
     }

@@ -76,10 +76,9 @@ int fill_kp(const mgs_forward_args& a, bool need_bins, bool need_outputs, KP& P)
   P.tile_offset = (int*)(g + L.tile_offset);
   P.tile_cursor = (int*)(g + L.tile_cursor);
   P.bin_table = (int*)(g + L.bin_table);
-  P.final_T = (float*)(g + L.final_T);
-  P.final_C = (float*)(g + L.final_C);
+  P.final_TC = (float4*)(g + L.final_TC);
+  P.final_DL = (int2*)(g + L.final_DL);
   P.seg_offset = (int*)(g + L.seg_offset);
-  P.n_contrib = (int*)(g + L.n_contrib);
   P.quad_last = (int*)(g + L.quad_last);
   P.counters = (int*)(g + L.counters);
   char* b = (char*)a.bins;
@@ -145,8 +144,8 @@ int32_t mgs_raster_workspace_query(const mgs_raster_shape* shape, mgs_workspace_
   out->geom_bytes = L.geom_bytes; out->bins_bytes = L.bins_bytes; out->bwd_bytes = L.bwd_bytes;
   out->sketch_bytes = L.sketch_bytes;
   out->off_records = L.rec; out->off_pair_count = L.pair_count;
-  out->off_tile_offset = L.tile_offset; out->off_final_T = L.final_T;
-  out->off_n_contrib = L.n_contrib; out->off_counters = L.counters;
+  out->off_tile_offset = L.tile_offset; out->off_final_T = L.final_TC;
+  out->off_n_contrib = L.final_DL; out->off_counters = L.counters;
   out->off_keys = L.keys; out->off_payload = L.payload;
   return MGS_OK;
 }

@@ -738,8 +738,9 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
   v2f mid_01 = {0.f, 0.f}, mid_2D = {0.f, 0.f};
   auto flush_mid = [&]() {
     if (sg_mid >= 0 && sg_mid < P.max_segs) {
-      float* ck = P.ckpt + (size_t)sg_mid * (5 * 256) + ptile;
-      ck[0] = mid_T; ck[256] = mid_01.x; ck[512] = mid_01.y; ck[768] = mid_2D.x; ck[1024] = mid_2D.y;
+      float* ck = P.ckpt + (size_t)sg_mid * (5 * 256);
+      reinterpret_cast<float4*>(ck)[ptile] = make_float4(mid_T, mid_01.x, mid_01.y, mid_2D.x);
+      ck[1024 + ptile] = mid_2D.y;
     }
     sg_mid = -1;
   };
@@ -774,8 +775,9 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
     if (base > 0 && base % kItem == 0) {   // checkpoint: state in front of this backward item
       const int sg = seg0 + base / kItem;
       if (sg < P.max_segs) {
-        float* ck = P.ckpt + (size_t)sg * (5 * 256) + ptile;
-        ck[0] = fabsf(T); ck[256] = C01.x; ck[512] = C01.y; ck[768] = C2D.x; ck[1024] = C2D.y;
+        float* ck = P.ckpt + (size_t)sg * (5 * 256);
+        reinterpret_cast<float4*>(ck)[ptile] = make_float4(fabsf(T), C01.x, C01.y, C2D.x);
+        ck[1024 + ptile] = C2D.y;
       }
     }
     // loads of the NEXT segment (records) and of the one after it (ids)
@@ -893,20 +895,25 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
   if (touched_prev > 0) atomicAdd(&P.n_touched[cid_prev], touched_prev);
   if constexpr (kParts > 1) flush_mid();
   {   // state for the backward, quadrant-major (coalesced); lanes outside the image hold last = 0
-    const size_t TQ = (size_t)256 * P.T, qi = (size_t)tile * 256 + ptile;
+    int lane_q = lane;
+    asm volatile("" : "+v"(lane_q));
+    const size_t qi = (size_t)tile * 256 + quad * 64 + lane_q;
     T = fabsf(T);
-    P.final_T[qi] = T;
-    P.n_contrib[qi] = last;
-    P.final_C[qi] = C01.x; P.final_C[TQ + qi] = C01.y;
-    P.final_C[2 * TQ + qi] = C2D.x; P.final_C[3 * TQ + qi] = C2D.y;
+    P.final_TC[qi] = make_float4(T, C01.x, C01.y, C2D.x);
+    P.final_DL[qi] = make_int2(__float_as_int(C2D.y), last);
     int m = last;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
     if (lane == 0) P.quad_last[4 * tile + quad] = m;
   }
-  if (inside) {
+  // the pixel position is derived again from the lane id (an opaque copy: otherwise px, py and
+  // the inside flag stay live across the whole walk and the kernel needs a scratch slot)
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  const int px_e = qx0 + (lane_e & 7), py_e = qy0 + (lane_e >> 3);
+  if (px_e < P.W && py_e < P.H) {
     const size_t HW = (size_t)P.W * P.H;
-    const size_t pix = (size_t)py * P.W + px;
+    const size_t pix = (size_t)py_e * P.W + px_e;
     P.out_color[pix] = C01.x + T * P.bg[0];
     P.out_color[HW + pix] = C01.y + T * P.bg[1];
     P.out_color[2 * HW + pix] = C2D.x + T * P.bg[2];

@@ -30,9 +30,8 @@ struct KP {
   // per-pixel results of the forward that only the backward reads, in QUADRANT-MAJOR order:
   // entry (tile * 4 + quadrant) * 64 + lane, lane = (y & 7) * 8 + (x & 7) - the order in which a
   // quadrant wave of either blend kernel holds its pixels, so every access is one coalesced 256-B run
-  float* final_T;          // [256 T]
-  float* final_C;          // [4][256 T] colour (without background) and depth at the end of the list
-  int* n_contrib;          // [256 T]
+  float4* final_TC;        // [256 T] (T, C0, C1, C2) at the end of the list (colour without background)
+  int2* final_DL;          // [256 T] (depth as float bits, n_contrib = position behind the last contribution)
   int* quad_last;          // [4 T] max of n_contrib over the quadrant: the list position behind which the
                            // quadrant is saturated (the backward skips it from there on)
   int* seg_offset;         // T+1: exclusive scan of ceil(n_t / kItem): first backward item of a tile
@@ -41,7 +40,7 @@ struct KP {
   unsigned long long* keys;
   unsigned int* payload;
   int4* seg_rec;           // backward item -> (tile, first key index, splats in the item, position in the list)
-  float* ckpt;             // per item: [5][256] blend state (T, C0, C1, C2, D) before its first splat
+  float* ckpt;             // per item: float4[256] (T, C0, C1, C2) then float[256] D: blend state before its first splat
   int max_segs;
   // forward outputs
   float *out_color, *out_depth, *out_opacity;
@@ -99,8 +98,8 @@ constexpr uint64_t kAlign = 256;
 inline uint64_t align_up(uint64_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
 
 struct Layout {
-  uint64_t rec, pair_count, pair_off, block_prefix, scan_tmp, tile_count, tile_offset, tile_cursor, bin_table, final_T, final_C,
-      n_contrib, quad_last, seg_offset, counters, geom_bytes;
+  uint64_t rec, pair_count, pair_off, block_prefix, scan_tmp, tile_count, tile_offset, tile_cursor, bin_table, final_TC, final_DL,
+      quad_last, seg_offset, counters, geom_bytes;
   uint64_t keys, payload, seg_rec, ckpt, max_segs, bins_bytes;
   uint64_t pair_grad, tau_partial, bwd_bytes;
   uint64_t pix_jac, splat_jac, sketch_bytes;
@@ -151,9 +150,8 @@ inline Layout make_layout(const mgs_raster_shape& s) {
   L.tile_offset = o; o = align_up(o + (T + 1) * 4);
   L.tile_cursor = o; o = align_up(o + T * 4);
   L.bin_table = o; o = align_up(o + (uint64_t)kBinBlocks * T * 4);
-  L.final_T = o; o = align_up(o + T * 256 * 4);
-  L.final_C = o; o = align_up(o + T * 256 * 16);
-  L.n_contrib = o; o = align_up(o + T * 256 * 4);
+  L.final_TC = o; o = align_up(o + T * 256 * 16);
+  L.final_DL = o; o = align_up(o + T * 256 * 8);
   L.quad_last = o; o = align_up(o + T * 4 * 4);
   L.seg_offset = o; o = align_up(o + (T + 1) * 4);
   L.counters = o; o = align_up(o + 16);
