@@ -131,7 +131,7 @@ struct BwdStamp {
 #define MGS_BWD_OCC 6
 #endif
 template <bool SKETCH, bool JONLY = false, bool POSE = false>
-__global__ __launch_bounds__(64, SKETCH ? 4 : (POSE ? 5 : MGS_BWD_OCC)) void k_blend_bwd(KP P, KB B) {
+__global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : (POSE ? 5 : MGS_BWD_OCC)) void k_blend_bwd(KP P, KB B) {
   MGS_BSTAMP;
   static_assert(SKETCH || !JONLY, "JONLY is a sketch-mode variant");
   static_assert(!(SKETCH && POSE), "POSE is a plain-mode variant");
@@ -139,15 +139,55 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : (POSE ? 5 : MGS_BWD_OCC)) void k_b
   __shared__ float4 s_r0[kSeg], s_r1[kSeg];
   __shared__ float2 s_r2[kSeg];             // 2560 B of LDS in all: 25 waves per CU
   __shared__ float4 s_coef[SKETCH ? kSeg : 1][9];   // per splat: 6 features x 6 tau components
+  // Sketch mode: a workgroup takes kSketchReps consecutive items (mostly of one tile) and adds its
+  // per-pixel Jacobian rows to pix_jac once per tile instead of once per item: the atomics, not the
+  // walk, bound that variant, and the 32-splat items doubled them.
+  constexpr int kReps = SKETCH ? kSketchReps : 1;
+  const int n_items = min(P.seg_offset[P.T], P.max_segs);
 #ifdef MGS_STAMP
-  int item = xcd_remap<kBwdChunk>(blockIdx.x);
+  int item_first = xcd_remap<kBwdChunk>(blockIdx.x) * kReps;
   const int lane = threadIdx.x;
-  if (g_item_order) item = g_item_order[item];
-  if (item < 0 || item >= min(P.seg_offset[P.T], P.max_segs)) return;
+  if (g_item_order && !SKETCH) item_first = g_item_order[item_first];
+  if (item_first < 0) return;
 #else
-  const int item = xcd_remap<kBwdChunk>(blockIdx.x), lane = threadIdx.x;
-  if (item >= min(P.seg_offset[P.T], P.max_segs)) return;
+  const int item_first = xcd_remap<kBwdChunk>(blockIdx.x) * kReps, lane = threadIdx.x;
 #endif
+  if (item_first >= n_items) return;
+  // sketch mode: per-pixel pose-Jacobian rows, as pairs (tau 0,1) (2,3) (4,5), of the tile in hand
+  v2f J2[SKETCH ? 4 : 1][3];
+#pragma unroll
+  for (int q = 0; q < (SKETCH ? 4 : 1); q++)
+#pragma unroll
+    for (int t = 0; t < 3; t++) J2[q][t] = v2f{0.f, 0.f};
+  unsigned int jq_mask = 0u;       // quadrants whose rows received a contribution
+  int jtile = -1;
+  auto flush_jacobian = [&]() {
+    if constexpr (SKETCH) {
+      if (jtile < 0) return;
+      // pixel rows of different items of a tile meet in pix_jac: float atomics, planar
+      // [6][H*W] so a wave instruction covers 8-pixel runs of contiguous addresses
+      const int fx = (jtile % P.grid_x) * kTile + (lane & 7), fy = (jtile / P.grid_x) * kTile + (lane >> 3);
+      const size_t HWf = (size_t)P.W * P.H;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        if ((jq_mask >> q) & 1u) {                  // else: nothing to add, the items never reached this quadrant
+          const int px = fx + 8 * (q & 1), py = fy + 8 * (q >> 1);
+          if (px < P.W && py < P.H) {
+            const size_t pix = (size_t)py * P.W + px;
+#pragma unroll
+            for (int t = 0; t < 6; t++) atomicAdd(&B.pix_jac[(size_t)t * HWf + pix], (t & 1) ? J2[q][t >> 1].y : J2[q][t >> 1].x);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 3; t++) J2[q][t] = v2f{0.f, 0.f};
+      }
+      jq_mask = 0u;
+    }
+  };
+  for (int rep = 0; rep < kReps; rep++) {
+  const int item = item_first + rep;
+  if (item >= n_items) break;
+  if (rep > 0) __syncthreads();      // single-wave workgroup: orders the reuse of the staged records
   // One 16-B record per item (written by the tile sort) instead of a chain of dependent loads:
   // tile, index of the item's first key, number of splats (<= kItem), position in the tile's list.
 #if defined(MGS_BPRIO)
@@ -161,10 +201,13 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : (POSE ? 5 : MGS_BWD_OCC)) void k_b
 #ifdef MGS_STAMP
   bstamp_.item_base = base;
 #endif
-  if (nb <= 0) return;
+  if (nb <= 0) continue;
 #if defined(MGS_ABL) && MGS_ABL == 10
-  return;
+  continue;
 #endif
+  if constexpr (SKETCH) {
+    if (tile != jtile) { flush_jacobian(); jtile = tile; }
+  }
   __builtin_assume(nb <= kItem);
   const int tx = tile % P.grid_x, ty = tile / P.grid_x;
   // Pixel q of this lane lies in QUADRANT q of the tile: (qx + 8 (q & 1), qy + 8 (q >> 1)).
@@ -264,12 +307,6 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : (POSE ? 5 : MGS_BWD_OCC)) void k_b
 #endif
 
   MGS_BMARK(0);
-  // sketch mode: per-pixel pose-Jacobian rows of this item, as pairs (tau 0,1) (2,3) (4,5)
-  v2f J2[SKETCH ? 4 : 1][3];
-#pragma unroll
-  for (int q = 0; q < (SKETCH ? 4 : 1); q++)
-#pragma unroll
-    for (int t = 0; t < 3; t++) J2[q][t] = v2f{0.f, 0.f};
   // reduce-scatter bookkeeping (wave_reduce.h): which of the ten sums this lane ends up with
   const unsigned long long b3mask = __ballot((lane & 8) != 0);
   const bool wextra = lane == 31 || lane == 63;
@@ -346,6 +383,7 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : (POSE ? 5 : MGS_BWD_OCC)) void k_b
         R89 = __builtin_elementwise_fma(ww, G2d[q], R89);
       }
       if constexpr (SKETCH) {
+        jq_mask |= 1u << q;      // wave-uniform: this quadrant's rows are non-zero
         // J_t += W (c0 dx + c1 dy + c2 dx^2 + c3 dx dy + c4 dy^2) + (w dL/dD) c5 for the six tau
         // components: the splat's 36 coefficients are staged in LDS in feature-major order, so two
         // tau components share one packed FMA (18 instead of 36 per quadrant)
@@ -483,19 +521,8 @@ __global__ __launch_bounds__(64, SKETCH ? 4 : (POSE ? 5 : MGS_BWD_OCC)) void k_b
 #if defined(MGS_ABL)
   if (T[0] == 123.456f && slot >= 0) B.pair_grad[(size_t)slot * 3].x = T[0] + T[1] + T[2] + T[3] + gS[0] + gS[1] + gS[2] + gS[3];
 #endif
-  if constexpr (SKETCH) {
-    // pixel rows of different items of a tile meet in pix_jac: float atomics, planar
-    // [6][H*W] so a wave instruction covers 8-pixel runs of contiguous addresses
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int px = qx + 8 * (q & 1), py = qy + 8 * (q >> 1);
-      if (px < P.W && py < P.H) {
-        const size_t pix = (size_t)py * P.W + px;
-#pragma unroll
-        for (int t = 0; t < 6; t++) atomicAdd(&B.pix_jac[(size_t)t * HW + pix], (t & 1) ? J2[q][t >> 1].y : J2[q][t >> 1].x);
-      }
-    }
-  }
+  }   // rep
+  flush_jacobian();
 }
 
 // ---------------------------------------------------------------------------------
@@ -839,9 +866,9 @@ int launch_backward(const KP& P, const KB& B, hipStream_t st, bool skip_tau_redu
       return MGS_ERR_LAUNCH;
     launch("sketch_prep", k_sketch_prep, dim3((P.N + kPreBlock - 1) / kPreBlock), dim3(kPreBlock), st, P, B);
     if (B.sketch_only)
-      launch("blend_bwd_sketch", k_blend_bwd<true, true>, dim3(grid_pad(P.max_segs, kBwdChunk)), dim3(64), st, P, B);
+      launch("blend_bwd_sketch", k_blend_bwd<true, true>, dim3(grid_pad((P.max_segs + kSketchReps - 1) / kSketchReps, kBwdChunk)), dim3(64), st, P, B);
     else
-      launch("blend_bwd_sketch", k_blend_bwd<true, false>, dim3(grid_pad(P.max_segs, kBwdChunk)), dim3(64), st, P, B);
+      launch("blend_bwd_sketch", k_blend_bwd<true, false>, dim3(grid_pad((P.max_segs + kSketchReps - 1) / kSketchReps, kBwdChunk)), dim3(64), st, P, B);
     launch_smem("sketch_bucket", k_sketch_bucket, dim3(kBucketBlocks), dim3(256), nacc * sizeof(float), st, P, B);
     if (B.sketch_only) return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
   } else {
