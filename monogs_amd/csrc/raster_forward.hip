@@ -1,18 +1,19 @@
 // Forward pass of the rasteriser for gfx950 (CDNA4, wave64).
 //
 // Pipeline (one launch each, all on the caller's stream, no host sync):
-//   k_preprocess     1 thread / Gaussian : projection + EWA -> 48-B SplatRec          (HBM bound)
-//   k_bin_lds<count> 1024-thread workgroup per contiguous chunk of Gaussians: exact tile culling,
-//                    per-chunk tile histogram in LDS (no global atomics), per-Gaussian slot offsets
+//   k_bin_lds<count> 1024-thread workgroup per contiguous chunk of Gaussians: projection + EWA -> 48-B
+//                    SplatRec, exact tile culling, per-chunk tile histogram in LDS (no global atomics),
+//                    per-Gaussian slot offsets
 //   k_bin_colsum     column prefix of the chunk histograms -> per-chunk bases and tile totals; the
 //                    workgroup that finishes last also scans the tile totals (-> tile_offset, D)
 //   k_bin_lds<emit>  same walk: (depth | id | pair index) keys into the tiles' ranges
-//   k_tile_sort      1 workgroup / tile  : LDS bitonic sort of the tile's range by (depth, id);
+//   k_tile_sort_reg  1 workgroup / tile  : register-resident bitonic sort of the tile's range by (depth, id)
+//                    (DPP / ds_bpermute exchanges; k_tile_sort: LDS / HBM network for tiles beyond 1024 pairs);
 //                    two size classes (<= 1024, <= 4096 keys), larger tiles sort in place in HBM
 //   k_blend_fwd      1 wave / 8x8 quadrant (its own 64-thread workgroup): front-to-back blend over
 //                    the tile's sorted list, 64 splats staged in LDS at a time, per-pixel state
-//                    checkpointed every 64 splats for the segment-parallel backward
-// (k_bin / k_scan_* / k_tile_scan: fallback for images with more tiles than fit an LDS table.)
+//                    checkpointed every kItem = 32 splats for the item-parallel backward
+// (k_preprocess / k_bin / k_scan_* / k_tile_scan: fallback for images with more tiles than fit an LDS table.)
 //
 // Replaces rasterize_gaussians (forward) of the reference's CUDA extension, called at
 // /root/reference gaussian_splatting/gaussian_renderer/__init__.py:151-168.
@@ -612,6 +613,152 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(KP P) {
 }
 
 // ---------------------------------------------------------------------------------
+// Register-resident sort of the common size class (n <= 1024): 256 threads, four consecutive
+// elements per thread.  The network is the one above (per merge size k: partner e ^ (k - 1), then
+// e ^ j for j = k/4 ... 1; the lower index keeps the smaller key), but an exchange only leaves the
+// registers when it has to:
+//   partner in the same thread (distances 1, 2, 3)         -> compare-exchange in registers
+//   partner in the same wave (lane xor 1 ... 63)           -> ds_bpermute (LDS crossbar, no memory,
+//                                                             no barrier)
+//   partner in another wave (k = 512, 1024: three stages)  -> through LDS with a barrier
+// 19 + 33 + 3 stages for 1024 keys instead of 55 LDS round trips.  Elements beyond n are
+// virtual +inf (no real key has all bits set: the depth word is a positive float).
+template <int CTRL, int BANK>
+__device__ __forceinline__ int dpp_move(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xF, BANK, false); }
+template <int X>
+__device__ __forceinline__ int lane_xor_dpp(int v) {     // value of lane (lane ^ X); checked on gfx950 for every X
+  if constexpr (X == 1) return dpp_move<0xB1, 0xF>(v, v);          // quad_perm [1,0,3,2]
+  else if constexpr (X == 2) return dpp_move<0x4E, 0xF>(v, v);     // quad_perm [2,3,0,1]
+  else if constexpr (X == 3) return dpp_move<0x1B, 0xF>(v, v);     // quad_perm [3,2,1,0]
+  else if constexpr (X == 7) return dpp_move<0x141, 0xF>(v, v);    // row_half_mirror
+  else if constexpr (X == 15) return dpp_move<0x140, 0xF>(v, v);   // row_mirror
+  else if constexpr (X == 8) return dpp_move<0x128, 0xF>(v, v);    // row_ror:8
+  else { static_assert(X == 4, "no DPP form"); const int t = dpp_move<0x12C, 0x5>(v, v); return dpp_move<0x124, 0xA>(t, v); }
+}
+
+template <bool PACKED>
+__global__ __launch_bounds__(256) void k_tile_sort_reg(KP P) {
+  __shared__ unsigned long long s_xk[1024];
+  __shared__ unsigned int s_xv[PACKED ? 1 : 1024];
+  const int tid = threadIdx.x, lane = tid & 63, tile = blockIdx.x;
+  int start = P.tile_offset[tile], end = P.tile_offset[tile + 1];
+  const int n_all = end - start;                    // as counted by the scans (seg_offset)
+  start = min(start, P.cap); end = min(end, P.cap);
+  const int n = end - start;
+  {   // item -> tile map for the item-parallel backward
+    // EVERY item the scan counted gets a record - also those cut off by an undersized pair
+    // capacity (0 splats), so that the backward never reads an unwritten record
+    const int s0 = P.seg_offset[tile], ns = (n_all + kItem - 1) / kItem;
+    for (int i = tid; i < ns; i += 256)
+      if (s0 + i < P.max_segs)
+        P.seg_rec[s0 + i] = make_int4(tile, min(start + i * kItem, P.cap), max(0, min(kItem, n - i * kItem)), i * kItem);
+  }
+  if (n <= 1) return;
+  unsigned long long* gk = P.keys + start;
+  unsigned int* gv = PACKED ? nullptr : P.payload + start;
+  if (n > 1024) {          // workgroup-uniform
+    if (!P.big_pass) bitonic_sort<false, !PACKED, 4>(gk, gv, n, tid);   // in place in HBM (no second launch)
+    return;
+  }
+  constexpr unsigned long long kInf = ~0ull;
+  unsigned long long k[4];
+  unsigned int v[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int e = 4 * tid + r;
+    k[r] = e < n ? gk[e] : kInf;
+    if constexpr (!PACKED) v[r] = e < n ? gv[e] : 0u;
+  }
+  int m = 4;
+  while (m < n) m <<= 1;
+  // compare-exchange inside the thread: the lower index keeps the smaller key
+  auto ce = [&](int a, int b) {
+    if (k[a] > k[b]) {
+      const unsigned long long t = k[a]; k[a] = k[b]; k[b] = t;
+      if constexpr (!PACKED) { const unsigned int u = v[a]; v[a] = v[b]; v[b] = u; }
+    }
+  };
+  // keep the smaller (lower thread) or the larger (upper thread) of own / partner element
+  auto keep = [&](int r, unsigned long long pk, unsigned int pv, bool lower) {
+    const bool take = (pk < k[r]) == lower;          // keys are unique
+    k[r] = take ? pk : k[r];
+    if constexpr (!PACKED) v[r] = take ? pv : v[r];
+  };
+  // exchange with thread tid ^ X (X > 0); FLIP: the partner of element r is the other thread's 3 - r
+  auto exchange = [&](auto flip_tag, int X) {
+    constexpr bool FLIP = decltype(flip_tag)::value;
+    // the thread with the lower index holds the lower elements: decided by the highest bit of X
+    const bool lower = (tid & (1 << (31 - __builtin_clz(X)))) == 0;
+    unsigned long long pk[4];
+    unsigned int pv[4] = {0u, 0u, 0u, 0u};
+    if (X < 64) {
+      // lane xor 1, 2, 3, 7, 8, 15 is one DPP move (quad_perm / row_half_mirror / row_ror:8 /
+      // row_mirror), xor 4 is two (row_ror:12 on banks 0 and 2, row_ror:4 on banks 1 and 3): VALU
+      // work of this SIMD.  The rest goes through ds_bpermute, whose throughput is shared by the
+      // whole CU and bounded the first version of this kernel (36 exchange stages x 8 dwords).
+      const int addr = (lane ^ X) << 2;
+      auto fetch_all = [&](auto xc) {           // one switch per stage, the eight moves below it
+        constexpr int XC = decltype(xc)::value;
+        auto from_partner = [&](int w) -> int {
+          if constexpr (XC == 0) return __builtin_amdgcn_ds_bpermute(addr, w);
+          else return lane_xor_dpp<XC>(w);
+        };
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const unsigned long long mine = k[FLIP ? 3 - r : r];
+          const unsigned int lo = (unsigned int)from_partner((int)(unsigned int)mine);
+          const unsigned int hi = (unsigned int)from_partner((int)(unsigned int)(mine >> 32));
+          pk[r] = ((unsigned long long)hi << 32) | lo;
+          if constexpr (!PACKED) pv[r] = (unsigned int)from_partner((int)v[FLIP ? 3 - r : r]);
+        }
+      };
+      switch (X) {
+        case 1: fetch_all(std::integral_constant<int, 1>{}); break;
+        case 2: fetch_all(std::integral_constant<int, 2>{}); break;
+        case 3: fetch_all(std::integral_constant<int, 3>{}); break;
+        case 4: fetch_all(std::integral_constant<int, 4>{}); break;
+        case 7: fetch_all(std::integral_constant<int, 7>{}); break;
+        case 8: fetch_all(std::integral_constant<int, 8>{}); break;
+        case 15: fetch_all(std::integral_constant<int, 15>{}); break;
+        default: fetch_all(std::integral_constant<int, 0>{}); break;
+      }
+    } else {
+      __syncthreads();                 // the previous exchange has been read
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        s_xk[4 * tid + r] = k[r];
+        if constexpr (!PACKED) s_xv[4 * tid + r] = v[r];
+      }
+      __syncthreads();
+      const int pt = tid ^ X;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        pk[r] = s_xk[4 * pt + (FLIP ? 3 - r : r)];
+        if constexpr (!PACKED) pv[r] = s_xv[4 * pt + (FLIP ? 3 - r : r)];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) keep(r, pk[r], pv[r], lower);
+  };
+  // merge sizes 2 and 4 stay inside the thread
+  ce(0, 1); ce(2, 3);
+  ce(0, 3); ce(1, 2); ce(0, 1); ce(2, 3);
+  for (int kk = 8; kk <= m; kk <<= 1) {
+    exchange(std::true_type{}, (kk - 1) >> 2);                          // partner e ^ (kk - 1)
+    for (int j = kk >> 2; j >= 4; j >>= 1) exchange(std::false_type{}, j >> 2);   // partner e ^ j
+    ce(0, 2); ce(1, 3); ce(0, 1); ce(2, 3);                             // j = 2, 1
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int e = 4 * tid + r;
+    if (e < n) {
+      gk[e] = k[r];
+      if constexpr (!PACKED) gv[e] = v[r];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // Front-to-back blend.  One WAVE per 8x8 quadrant of a tile (one pixel per lane), launched
 // as its own 64-thread workgroup: the four quadrant waves of a tile are fully independent,
 // so there is no workgroup barrier anywhere, a saturated quadrant retires at once, and the
@@ -990,10 +1137,10 @@ int launch_forward_blend(const KP& P, hipStream_t st) {
   // (crowded tiles get 1024 threads: 16 waves on the 4096-key network - 170 -> ~35 us when every
   // tile of a 320x240 view holds ~2500 splats)
   if (P.pack) {
-    launch("tile_sort", k_tile_sort<1024, 0, true, 256>, dim3(P.T), dim3(256), st, P);
+    launch("tile_sort", k_tile_sort_reg<true>, dim3(P.T), dim3(256), st, P);
     if (P.big_pass) launch("tile_sort_big", k_tile_sort<4096, 1024, true, 1024>, dim3(min(P.T, 512)), dim3(1024), st, P);
   } else {
-    launch("tile_sort", k_tile_sort<1024, 0, false, 256>, dim3(P.T), dim3(256), st, P);
+    launch("tile_sort", k_tile_sort_reg<false>, dim3(P.T), dim3(256), st, P);
     if (P.big_pass) launch("tile_sort_big", k_tile_sort<4096, 1024, false, 1024>, dim3(min(P.T, 512)), dim3(1024), st, P);
   }
   launch("blend_fwd", k_blend_fwd, dim3(grid_pad(4 * P.T, kFwdChunk)), dim3(64), st, P);

@@ -53,6 +53,9 @@ __global__ void k(long long* out, float* sink, int iters, float seed) {
     if (KIND == 31) asm volatile(REP16("v_mul_f32 %0, %0, %1\n v_fma_f32 %3, %3, %1, %2\n v_fma_f32 %4, %4, %1, %2\n v_fma_f32 %5, %5, %1, %2\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
     if (KIND == 32) asm volatile(REP16("v_mul_f32 %0, %0, %1\n v_mul_f32 %3, %3, %1\n v_fma_f32 %4, %4, %1, %2\n v_fma_f32 %5, %5, %1, %2\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
     if (KIND == 33) asm volatile(REP16("v_pk_fma_f32 %0, %0, %1, %2\n v_mul_f32 %4, %4, %5\n v_pk_fma_f32 %3, %3, %1, %2\n v_mul_f32 %5, %5, %4\n") : "+v"(*(double*)&a), "+v"(*(double*)&c), "+v"(*(double*)&e), "+v"(*(double*)&g), "+v"(d), "+v"(h));
+    if (KIND == 34) asm volatile(REP16("v_cmp_lt_u64_e64 s[20:21], %0, %1\n v_cmp_lt_u64_e64 s[22:23], %1, %2\n v_cmp_lt_u64_e64 s[24:25], %2, %3\n v_cmp_lt_u64_e64 s[26:27], %3, %0\n") : "+v"(*(double*)&a), "+v"(*(double*)&c), "+v"(*(double*)&e), "+v"(*(double*)&g) :: "s20","s21","s22","s23","s24","s25","s26","s27");
+    if (KIND == 35) asm volatile(REP16("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %4, %5 row_mirror row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %0 row_ror:4 row_mask:0xf bank_mask:0x5\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
+    if (KIND == 36) asm volatile(REP16("ds_bpermute_b32 %0, %1, %0\n ds_bpermute_b32 %3, %1, %3\n ds_bpermute_b32 %4, %1, %4\n ds_bpermute_b32 %5, %1, %5\n s_waitcnt lgkmcnt(0)\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
   }
   const long long t1 = __builtin_amdgcn_s_memtime();
   if (threadIdx.x % 64 == 0) out[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
@@ -116,5 +119,8 @@ int main(int argc, char** argv) {
   RUN(31, "1 mul + 3 fma", 64);
   RUN(32, "2 mul + 2 fma", 64);
   RUN(33, "pk_fma + mul alternating", 64);
+  RUN(34, "v_cmp_lt_u64 -> sgpr", 64);
+  RUN(35, "v_mov_b32_dpp", 64);
+  RUN(36, "ds_bpermute_b32 (4 + wait)", 64);
   return 0;
 }
