@@ -127,11 +127,8 @@ struct BwdStamp {
 #define MGS_BCOUNT(v, a)
 #endif
 
-#ifndef MGS_BWD_OCC
-#define MGS_BWD_OCC 6
-#endif
 template <bool SKETCH, bool JONLY = false, bool POSE = false>
-__global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : (POSE ? 5 : MGS_BWD_OCC)) void k_blend_bwd(KP P, KB B) {
+__global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : (POSE ? 5 : 6)) void k_blend_bwd(KP P, KB B) {
   MGS_BSTAMP;
   static_assert(SKETCH || !JONLY, "JONLY is a sketch-mode variant");
   static_assert(!(SKETCH && POSE), "POSE is a plain-mode variant");
@@ -190,9 +187,6 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : (POSE ? 5 : MGS_BWD_
   if (rep > 0) __syncthreads();      // single-wave workgroup: orders the reuse of the staged records
   // One 16-B record per item (written by the tile sort) instead of a chain of dependent loads:
   // tile, index of the item's first key, number of splats (<= kItem), position in the tile's list.
-#if defined(MGS_BPRIO)
-  __builtin_amdgcn_s_setprio(MGS_BPRIO == 1 ? 3 : 0);
-#endif
 #ifdef MGS_STAMP
   bstamp_.item_id = item;
 #endif
@@ -347,10 +341,12 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : (POSE ? 5 : MGS_BWD_
       any = true; r0 += u.x; continue;
 #endif
       const v2f d = mu - Pq[q];
-      const float pw = d.x * (u.z * d.x + u.w * d.y) + v.x * d.y * d.y;
+      // clamped at 0 like the forward's form of the exponent (the quadratic form is <= 0; only
+      // rounding can make it positive)
+      const float pw = fminf(0.f, d.x * (u.z * d.x + u.w * d.y) + v.x * d.y * d.y);
       const float ar = v.y * __builtin_amdgcn_exp2f(pw);
       const float al = fminf(kAlphaMax, ar);
-      const bool k = idx < last[q] && pw <= 0.f && al >= kAlphaMin;
+      const bool k = idx < last[q] && al >= kAlphaMin;
 #ifdef MGS_STAMP
       if (__ballot(k) == 0ull) bstamp_.nmiss++;
       bstamp_.nlanes += __popcll(__ballot(k));
@@ -477,9 +473,6 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : (POSE ? 5 : MGS_BWD_
       unsigned long long todo = mq[0] | mq[1] | mq[2] | mq[3];
       MGS_BMARK(1);
       MGS_BCOUNT(__popcll(mq[0]) + __popcll(mq[1]) + __popcll(mq[2]) + __popcll(mq[3]), __popcll(todo));
-#if defined(MGS_BPRIO)
-      __builtin_amdgcn_s_setprio(MGS_BPRIO == 1 ? 0 : 3);
-#endif
 #if defined(MGS_ABL) && (MGS_ABL == 4 || MGS_ABL == 12)
       todo = 0ull;
       T[0] += s_r0[lane ^ 1].x + s_r1[lane ^ 1].y + s_r2[lane ^ 1].x + (float)(mq[0] + mq[1] + mq[2] + mq[3]);
