@@ -128,7 +128,7 @@ struct BwdStamp {
 #endif
 
 template <bool SKETCH, bool JONLY = false, bool POSE = false>
-__global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : (POSE ? 5 : 6)) void k_blend_bwd(KP P, KB B) {
+__global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(KP P, KB B) {
   MGS_BSTAMP;
   static_assert(SKETCH || !JONLY, "JONLY is a sketch-mode variant");
   static_assert(!(SKETCH && POSE), "POSE is a plain-mode variant");

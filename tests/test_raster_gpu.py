@@ -527,6 +527,23 @@ def test_crowded_tiles_use_the_in_memory_sort_path(built):
     assert R.last_stats["pairs"] > 4 * 4096
 
 
+@pytest.mark.parametrize("N", [3, 7, 20, 45, 90, 180, 350, 700, 1200, 2400])
+def test_register_sort_merge_sizes(built, N):
+    """One 16 x 16 tile holding ~0.7 N splats: every merge size of k_tile_sort_reg (4 ... 1024 keys: in-thread
+    compare-exchanges, DPP lane distances 1 / 2 / 3 / 4 / 7 / 8 / 15, ds_bpermute 16 / 31 / 32 / 63, LDS across
+    waves) and, at 2400, the in-place HBM network.  The blend is order-sensitive, the emulation sorts with
+    std::sort; low opacity keeps every splat of the list contributing."""
+    from monogs_amd import synthetic as S
+    sc = S.make_scene(N, 16, 16, seed=300 + N)
+    m, s, r, o, sh = _inputs(sc)
+    from monogs_amd import rasterizer as R
+    _against_emulation(sc, m, s, r, o * (0.6 if N < 50 else 0.02), sh)
+    if N == 2400:
+        assert R.last_stats["pairs"] > 1024          # the HBM network of the first launch
+    if N == 1200:
+        assert 512 < R.last_stats["pairs"] <= 1024   # the full 1024-key register network
+
+
 def test_screen_filling_splats_use_the_wave_cooperative_binning(built):
     from monogs_amd import synthetic as S
     sc = S.make_scene(1500, 160, 120, seed=32)
