@@ -56,7 +56,7 @@ typedef struct mgs_raster_shape {
 typedef struct mgs_workspace_sizes {
   uint64_t geom_bytes;   /* per-Gaussian records, per-tile ranges, per-pixel blend state;
                             written by forward, read by backward (save it on the autograd ctx) */
-  uint64_t bins_bytes;   /* pair_capacity sorted (key, payload) pairs; forward -> backward */
+  uint64_t bins_bytes;   /* pair_capacity sorted (key, payload) pairs + per-item records and blend checkpoints (5 KB per 32 pairs and per tile); forward -> backward */
   uint64_t bwd_bytes;    /* backward-only scratch (per-pair reduced gradients, scans) */
   uint64_t sketch_bytes; /* extra backward scratch, only when sketch_mode != 0 */
   /* byte offsets inside `geom` of arrays tests may inspect */
