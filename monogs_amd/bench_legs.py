@@ -59,14 +59,17 @@ def bench_mapping(sc, dev, iters: int = 10):
                 mp.add_keyframe(i, v)
             mp.set_window(list(range(7, -1, -1)))
 
-            def it():
-                mp.map(iters=1)
+            def it(n=1):
+                mp.map(iters=n)       # ONE map() call runs n iterations, as the backend does per keyframe
         for _ in range(2):
             it()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(iters):
-            it()
+        if mode == "python":
+            for _ in range(iters):
+                it()
+        else:
+            it(iters)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         out[f"{mode}_iters_per_s"] = round(iters / dt, 2)

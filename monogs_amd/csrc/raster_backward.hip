@@ -617,7 +617,9 @@ __global__ __launch_bounds__(256) void k_sketch_bucket(KP P, KB B) {
 // regulariser's gradient (slam_backend.py:244-246) and this view's densification statistics
 // (gaussian_model.py:693-697, slam_backend.py:292-299) and occ-aware visibility (:251-255).
 // (no waves-per-SIMD bound: with an explicit 4 the same kernel ran 26 -> 35 us, with 5 or 6 it spills)
-template <bool MAP>
+// SH0 (mapping mode): active SH degree 0 - the colour gradient is three scalars; the general form
+// keeps a 48-entry coefficient array that lives in scratch memory.
+template <bool MAP, bool SH0 = false>
 __global__ __launch_bounds__(kPreBlock) void k_preprocess_bwd(KP P, KB B) {
   __shared__ float s_tau[kPreBlock / 64][6];
   const int idx = blockIdx.x * kPreBlock + threadIdx.x;
@@ -710,7 +712,17 @@ __global__ __launch_bounds__(kPreBlock) void k_preprocess_bwd(KP P, KB B) {
       const bool add = M.accumulate != 0;
       auto put = [&](float* dst, float v) { *dst = add ? *dst + v : v; };
       // colour coefficients first: for degree > 0 sh_backward adds the view-direction term to dmean
-      {
+      if constexpr (SH0) {
+        float d3[3] = {0.f, 0.f, 0.f};
+        if (radius > 0 && P.shs) {
+#pragma unroll
+          for (int c = 0; c < 3; c++) d3[c] = (flags & (1u << c)) ? 0.f : SH_C0 * grgb[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) put(&M.g_fdc[3 * (size_t)idx + c], d3[c]);
+        if (M.g_frest)      // stored degree above the active one: the higher bands get no gradient
+          for (int k = 3; k < 3 * P.K; k++) put(&M.g_frest[(size_t)3 * (P.K - 1) * idx + (k - 3)], 0.f);
+      } else {
         float dsh[48];
         if (radius > 0 && P.shs) {
           if (P.deg == 0) {
@@ -876,7 +888,8 @@ int launch_backward(const KP& P, const KB& B, hipStream_t st, bool skip_tau_redu
       launch("blend_bwd", k_blend_bwd<false, false, true>, dim3(grid_pad(P.max_segs, kBwdChunk)), dim3(64), st, P, B);
   }
   const int npre = (P.N + kPreBlock - 1) / kPreBlock;
-  if (B.map.on) launch("preprocess_bwd_map", k_preprocess_bwd<true>, dim3(npre), dim3(kPreBlock), st, P, B);
+  if (B.map.on && P.deg == 0) launch("preprocess_bwd_map", k_preprocess_bwd<true, true>, dim3(npre), dim3(kPreBlock), st, P, B);
+  else if (B.map.on) launch("preprocess_bwd_map", k_preprocess_bwd<true, false>, dim3(npre), dim3(kPreBlock), st, P, B);
   else launch("preprocess_bwd", k_preprocess_bwd<false>, dim3(npre), dim3(kPreBlock), st, P, B);
   if (!skip_tau_reduce) launch("tau_reduce", k_tau_reduce, dim3(1), dim3(768), st, B, npre);
   return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
