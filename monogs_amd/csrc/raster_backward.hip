@@ -790,12 +790,12 @@ __global__ __launch_bounds__(kPreBlock) void k_preprocess_bwd(KP P, KB B) {
     if (P.shs) {
       float* dsh = B.g_colors + (size_t)3 * P.K * idx;
       if (radius > 0) {
-        if (P.deg == 0) {
+        if (SH0 || P.deg == 0) {
 #pragma unroll
           for (int c = 0; c < 3; c++) dsh[c] = (flags & (1u << c)) ? 0.f : SH_C0 * grgb[c];
           for (int k = 3; k < 3 * P.K; k++) dsh[k] = 0.f;
         } else {
-          sh_backward(P.deg, P.K, P.shs + (size_t)3 * P.K * idx, p, P.campos, flags, grgb, dsh, dmean);
+          if constexpr (!SH0) sh_backward(P.deg, P.K, P.shs + (size_t)3 * P.K * idx, p, P.campos, flags, grgb, dsh, dmean);
         }
       } else {
         for (int k = 0; k < 3 * P.K; k++) dsh[k] = 0.f;
@@ -890,7 +890,8 @@ int launch_backward(const KP& P, const KB& B, hipStream_t st, bool skip_tau_redu
   const int npre = (P.N + kPreBlock - 1) / kPreBlock;
   if (B.map.on && P.deg == 0) launch("preprocess_bwd_map", k_preprocess_bwd<true, true>, dim3(npre), dim3(kPreBlock), st, P, B);
   else if (B.map.on) launch("preprocess_bwd_map", k_preprocess_bwd<true, false>, dim3(npre), dim3(kPreBlock), st, P, B);
-  else launch("preprocess_bwd", k_preprocess_bwd<false>, dim3(npre), dim3(kPreBlock), st, P, B);
+  else if (!P.shs || P.deg == 0) launch("preprocess_bwd", k_preprocess_bwd<false, true>, dim3(npre), dim3(kPreBlock), st, P, B);
+  else launch("preprocess_bwd", k_preprocess_bwd<false, false>, dim3(npre), dim3(kPreBlock), st, P, B);
   if (!skip_tau_reduce) launch("tau_reduce", k_tau_reduce, dim3(1), dim3(768), st, B, npre);
   return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
 }
