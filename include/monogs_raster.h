@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MGS_ABI_VERSION 4
+#define MGS_ABI_VERSION 5
 
 typedef enum mgs_status {
   MGS_OK = 0,
@@ -265,6 +265,15 @@ typedef struct mgs_pose_adam_args {
   float loss_w_rgb, loss_w_depth;
   float* loss_view;
   float* loss_accum;
+  /* loss_norm_mode == 1 (mgs_tracking_iteration): loss_partials are [n] block sums of the squared
+   * tracking residuals written by mgs_tracking_loss_onepass together with UN-normalised gradients
+   * (the objective is the norm sqrt(sum h^2), its gradient carries 1 / loss; everything between
+   * the loss and this kernel is linear in the image gradient).  This kernel forms loss = sqrt(sum),
+   * scales every gradient it sums by (*loss_grad_out or 1) / loss before the Adam step and stores
+   * loss and 1 / loss to loss_view[0], loss_view[1]. */
+  const float* loss_grad_out;
+  int32_t loss_norm_mode;
+  int32_t reserved0;
 } mgs_pose_adam_args;
 
 int32_t mgs_pose_adam_step(const mgs_pose_adam_args* args, void* stream);
@@ -369,6 +378,12 @@ int32_t mgs_tracking_loss_backward(const mgs_tracking_loss_args* args, void* str
  * left at partial[n .. 3n) ([2, n]: d/da then d/db, n = *num_blocks_out) for a consumer that
  * sums them (mgs_pose_adam_step: exposure_partials).  grad_a / grad_b are not written. */
 int32_t mgs_tracking_loss_fused(const mgs_tracking_loss_args* args, int32_t* num_blocks_out, void* stream);
+/* ONE launch: block sums of the squared residuals ([n] at partial), UN-normalised image gradient
+ * (as if loss were 1) and un-normalised exposure partials ([2,n] at partial + n).  The consumer
+ * (mgs_pose_adam_step with loss_norm_mode = 1) applies grad_out / loss.  args->scalars is not
+ * written here.  Replaces the two launches of mgs_tracking_loss_fused inside
+ * mgs_tracking_iteration (reference: utils/slam_utils.py:188-217 get_loss_tracking_rgb + autograd). */
+int32_t mgs_tracking_loss_onepass(const mgs_tracking_loss_args* args, int32_t* num_blocks_out, void* stream);
 
 
 /* ---- native tracking iteration (row a12: utils/slam_frontend.py:493-630) ---------------- */
@@ -385,7 +400,7 @@ int32_t mgs_camera_from_pose(const float* T, const float* projection, float* vie
  *   camera matrices from T -> rasteriser forward (project + blend at the caller's fixed
  *   pair capacity) -> tracking objective (mgs_tracking_loss_*) -> pose-only rasteriser
  *   backward -> Adam on (rot, trans, exposure a, b) + update_pose (mgs_pose_adam_step), with
- *   the small reduction kernels folded into their consumers (14 launches).
+ *   the small reduction kernels and the 1 / loss of the norm folded into their consumers (10 launches).
  * fwd.viewmatrix / fwd.projmatrix / fwd.campos must point at caller-owned device buffers
  * (16/16/>=3 floats; campos may alias viewmatrix) that this call REWRITES from T;
  * fwd.projmatrix_raw is the projection.  The forward is complete iff counters[0] (pair

@@ -13,14 +13,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MGS_LIB_PATH: load another build of the SAME library (kernel experiments, the -DMGS_STAMP build)
 LIB_PATH = os.environ.get("MGS_LIB_PATH") or os.path.join(_HERE, "lib", "libmonogs_raster.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 EXPORTS = (
     "mgs_abi_version", "mgs_struct_size", "mgs_status_string", "mgs_raster_workspace_query",
     "mgs_raster_forward_project", "mgs_raster_forward_blend", "mgs_raster_backward",
     "mgs_knn_scratch_bytes", "mgs_knn_dist2", "mgs_profile_enable", "mgs_profile_read",
     "mgs_pose_adam_step", "mgs_tracking_loss_partial_count", "mgs_tracking_loss_forward",
-    "mgs_tracking_loss_backward", "mgs_tracking_loss_fused", "mgs_lm_solve_step", "mgs_mapping_loss_forward",
+    "mgs_tracking_loss_backward", "mgs_tracking_loss_fused", "mgs_tracking_loss_onepass", "mgs_lm_solve_step", "mgs_mapping_loss_forward",
     "mgs_mapping_loss_backward", "mgs_camera_from_pose", "mgs_tracking_iteration",
     "mgs_adam_step_multi", "mgs_map_plan_blocks", "mgs_map_plan_count", "mgs_map_plan_emit",
     "mgs_map_gather", "mgs_pack_mapping_grads", "mgs_sketch_assign", "mgs_sketch_residual",
@@ -81,7 +81,8 @@ class PoseAdamArgs(C.Structure):
            ("num_exposure_partials", C.c_int32), ("projection", _fp), ("viewmatrix_out", _fp),
            ("projmatrix_out", _fp), ("no_pose_update", C.c_int32), ("loss_partials", _fp),
            ("num_loss_partials", C.c_int32), ("loss_w_rgb", C.c_float), ("loss_w_depth", C.c_float),
-           ("loss_view", _fp), ("loss_accum", _fp)])
+           ("loss_view", _fp), ("loss_accum", _fp), ("loss_grad_out", _fp),
+           ("loss_norm_mode", C.c_int32), ("reserved0", C.c_int32)])
 
 
 class MappingLossArgs(C.Structure):
@@ -208,6 +209,8 @@ def lib():
                                       C.c_void_p]
     L.mgs_tracking_loss_fused.restype = C.c_int32
     L.mgs_tracking_loss_fused.argtypes = [C.POINTER(TrackingLossArgs), C.POINTER(C.c_int32), C.c_void_p]
+    L.mgs_tracking_loss_onepass.restype = C.c_int32
+    L.mgs_tracking_loss_onepass.argtypes = [C.POINTER(TrackingLossArgs), C.POINTER(C.c_int32), C.c_void_p]
     L.mgs_sketch_assign.restype = C.c_int32
     L.mgs_sketch_assign.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p,
                                     C.c_void_p]

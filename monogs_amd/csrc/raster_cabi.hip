@@ -241,9 +241,10 @@ int32_t mgs_tracking_iteration(const mgs_tracking_iter_args* args, void* stream)
       !args->one || !args->adam.T || !args->fwd.viewmatrix || !args->fwd.projmatrix)
     return MGS_ERR_BAD_ARGUMENT;
   if (args->fwd.shape.pair_capacity < 1) return MGS_ERR_BAD_ARGUMENT;
-  // 14 launches: camera matrices (unless the caller says they are valid - the previous
-  // iteration's Adam kernel has already written them), 7 forward, 2 loss, 2 backward, 1 Adam + update_pose
-  // (which also sums the tau / exposure block partials and refreshes the camera matrices).
+  // 10 launches: camera matrices (unless the caller says they are valid - the previous
+  // iteration's Adam kernel has already written them), 5 forward, 1 loss (un-normalised gradients),
+  // 2 backward, 1 Adam + update_pose (which also sums the tau / exposure / squared-residual block
+  // partials, applies the 1 / loss of the norm and refreshes the camera matrices).
   int32_t rc = MGS_OK;
   if (!args->camera_matrices_valid) {
     rc = mgs_camera_from_pose(args->adam.T, args->fwd.projmatrix_raw, const_cast<float*>(args->fwd.viewmatrix),
@@ -257,7 +258,7 @@ int32_t mgs_tracking_iteration(const mgs_tracking_iter_args* args, void* stream)
   L.grad_out = args->one; L.grad_image = args->grad_image;
   L.grad_a = args->grad_exposure; L.grad_b = args->grad_exposure + 1;
   int32_t nblk = 0;
-  if ((rc = mgs_tracking_loss_fused(&L, &nblk, stream)) != MGS_OK) return rc;
+  if ((rc = mgs_tracking_loss_onepass(&L, &nblk, stream)) != MGS_OK) return rc;
   mgs_backward_args B;
   memset(&B, 0, sizeof(B));
   B.fwd = args->fwd;
@@ -271,6 +272,9 @@ int32_t mgs_tracking_iteration(const mgs_tracking_iter_args* args, void* stream)
   A.grad_trans = nullptr; A.grad_rot = nullptr; A.grad_a = nullptr; A.grad_b = nullptr;
   A.tau_partials = tau_partials; A.num_tau_partials = npre;
   A.exposure_partials = L.partial + nblk; A.num_exposure_partials = nblk;
+  A.loss_partials = L.partial; A.num_loss_partials = nblk;
+  A.loss_norm_mode = 1; A.loss_grad_out = args->one;
+  A.loss_view = L.scalars; A.loss_accum = nullptr;
   A.projection = args->fwd.projmatrix_raw;
   A.viewmatrix_out = const_cast<float*>(args->fwd.viewmatrix);
   A.projmatrix_out = const_cast<float*>(args->fwd.projmatrix);

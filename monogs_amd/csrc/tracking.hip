@@ -59,7 +59,7 @@ __global__ __launch_bounds__(512) void k_pose_adam_update(mgs_pose_adam_args A) 
     if (lane == 0) s_g[6 + c] = v;
   }
   __shared__ float s_loss[2];
-  if (A.loss_partials && wave >= 6) {      // mapping objective: colour / depth block sums
+  if (A.loss_partials && wave >= 6 && (A.loss_norm_mode == 0 || wave == 6)) {   // colour / depth block sums, or sum h^2
     const int c = wave - 6;
     float v = 0.f;
 #pragma unroll 8
@@ -69,7 +69,14 @@ __global__ __launch_bounds__(512) void k_pose_adam_update(mgs_pose_adam_args A) 
   }
   __syncthreads();
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (A.loss_partials) {
+  float grad_scale = 1.f;
+  if (A.loss_partials && A.loss_norm_mode == 1) {
+    // tracking objective = sqrt(sum h^2): the gradients summed above lack its 1 / loss
+    const float l = sqrtf(s_loss[0]);
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    grad_scale = inv * (A.loss_grad_out ? A.loss_grad_out[0] : 1.f);
+    if (A.loss_view) { A.loss_view[0] = l; A.loss_view[1] = inv; }
+  } else if (A.loss_partials) {
     const float l = A.loss_w_rgb * s_loss[0] + A.loss_w_depth * s_loss[1];
     if (A.loss_view) A.loss_view[0] = l;
     if (A.loss_accum) A.loss_accum[0] += l;
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(512) void k_pose_adam_update(mgs_pose_adam_args A) 
       const int o = first[g] + i;
       on[o] = G[g] != nullptr && P[g] != nullptr;
       p[o] = P[g] ? P[g][i] : 0.f;
-      gr[o] = on[o] ? G[g][i] : 0.f;
+      gr[o] = on[o] ? G[g][i] * grad_scale : 0.f;
       m[o] = A.exp_avg[o];
       v[o] = A.exp_avg_sq[o];
     }
@@ -276,6 +283,40 @@ __global__ __launch_bounds__(kLossBlock) void k_track_loss_bwd_finish(mgs_tracki
   const float ta = block_sum(x, s_red);
   const float tb = block_sum(y, s_red);
   if (threadIdx.x == 0) { A.grad_a[0] = ta; A.grad_b[0] = tb; }
+}
+
+// One pass (mgs_tracking_loss_onepass): block sums of h^2, the image gradient and the exposure
+// partials WITHOUT the 1 / loss factor of the norm's derivative; k_pose_adam_update applies it
+// (loss_norm_mode).  partial = [n] sum h^2 | [n] d/da | [n] d/db.
+__global__ __launch_bounds__(kLossBlock) void k_track_loss_onepass(mgs_tracking_loss_args A) {
+  __shared__ float s_red[kLossBlock / 64];
+  const float a = A.exposure_a[0];
+  const float gain = fabsf(a) + A.exposure_eps, bias = A.exposure_b[0];
+  const float sgn = a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f);
+  const size_t HW = (size_t)A.num_pixels;
+  float acc = 0.f, ga = 0.f, gb = 0.f;
+  for (size_t p = (size_t)blockIdx.x * kLossBlock + threadIdx.x; p < HW; p += (size_t)gridDim.x * kLossBlock) {
+    const float om = A.opacity[p] * (A.mask ? A.mask[p] : 1.f);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float im = A.image[c * HW + p];
+      float dh;
+      const float h = huber(om * (gain * im + bias - A.gt[c * HW + p]), A.huber_delta, dh);
+      acc += h * h;
+      const float gr = h * dh * om;
+      A.grad_image[c * HW + p] = gr * gain;
+      ga += gr * im;
+      gb += gr;
+    }
+  }
+  const float t = block_sum(acc, s_red);
+  const float ta = block_sum(ga, s_red);
+  const float tb = block_sum(gb, s_red);
+  if (threadIdx.x == 0) {
+    A.partial[blockIdx.x] = t;
+    A.partial[gridDim.x + blockIdx.x] = ta * sgn;
+    A.partial[2 * gridDim.x + blockIdx.x] = tb;
+  }
 }
 
 // ---------------------------------------------------------------------------------
@@ -785,6 +826,16 @@ int32_t mgs_tracking_loss_fused(const mgs_tracking_loss_args* a, int32_t* nblk_o
   const int nb = loss_blocks(a->num_pixels);
   launch("track_loss_fwd", k_track_loss_fwd, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a);
   launch("track_loss_bwd", k_track_loss_bwd, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a, nb);
+  if (nblk_out) *nblk_out = nb;
+  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+}
+
+int32_t mgs_tracking_loss_onepass(const mgs_tracking_loss_args* a, int32_t* nblk_out, void* stream) {
+  if (!a || !a->image || !a->opacity || !a->gt || !a->exposure_a || !a->exposure_b || !a->partial ||
+      !a->grad_image || a->num_pixels < 1)
+    return MGS_ERR_BAD_ARGUMENT;
+  const int nb = loss_blocks(a->num_pixels);
+  launch("track_loss", k_track_loss_onepass, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a);
   if (nblk_out) *nblk_out = nb;
   return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
 }
