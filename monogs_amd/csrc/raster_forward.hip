@@ -318,25 +318,12 @@ __global__ __launch_bounds__(256) void k_scan_write(KP P) {
 // Exclusive scans of the T tile counts (-> tile_offset, D) and of the per-tile segment
 // backward item counts ceil(n_t / kItem) (-> seg_offset) by one 1024-thread workgroup.
 __device__ __forceinline__ void tile_scan_body(const KP& P, int nbin, int* s_sum, int* s_seg) {
-  __shared__ int s_tmax;
-  const int tid = threadIdx.x;
-  if (tid == 0) s_tmax = 0;
-  __syncthreads();
-  if (nbin > 0) {   // exclusive scan of the binning blocks' pair totals (nbin <= 1024)
-    const int v = tid < nbin ? P.scan_tmp[tid] : 0;
-    s_sum[tid] = v;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-      const int t = (tid >= off) ? s_sum[tid - off] : 0;
-      __syncthreads();
-      s_sum[tid] += t;
-      __syncthreads();
-    }
-    if (tid < nbin) P.block_prefix[tid] = s_sum[tid] - v;
-    __syncthreads();
-  } else if (tid == 0) {   // fallback path: pair_off already holds the global scan
-    P.block_prefix[0] = 0;
-  }
+  // Three exclusive scans over the 1024 threads at once (binning-block totals, tile pair counts,
+  // tile item counts) + the largest tile: inclusive scans inside each wave with shuffles, the sixteen
+  // wave totals through LDS - ONE workgroup barrier (the Hillis-Steele form took forty).
+  int* s_w = s_sum;            // [4][16]: wave totals of the three scans, wave maxima
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int vb = (nbin > 0 && tid < nbin) ? P.scan_tmp[tid] : 0;     // nbin <= 1024
   const int per = (P.T + 1023) / 1024;
   const int lo = tid * per, hi = min(lo + per, P.T);
   int local = 0, lseg = 0, lmax = 0;
@@ -346,23 +333,31 @@ __device__ __forceinline__ void tile_scan_body(const KP& P, int nbin, int* s_sum
     lseg += (c + kItem - 1) / kItem;
     lmax = max(lmax, c);
   }
-  if (P.d_out) {   // largest tile, for the caller's choice of sort launches
+  int ib = vb, ip = local, is = lseg;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) lmax = max(lmax, __shfl_xor(lmax, off));
-    if ((tid & 63) == 0 && lmax > 0) atomicMax(&s_tmax, lmax);   // LDS; read behind the scan's barriers
+  for (int off = 1; off < 64; off <<= 1) {
+    const int tb = __shfl_up(ib, off), tp = __shfl_up(ip, off), ts = __shfl_up(is, off);
+    if (lane >= off) { ib += tb; ip += tp; is += ts; }
   }
-  s_sum[tid] = local;
-  s_seg[tid] = lseg;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) lmax = max(lmax, __shfl_xor(lmax, off));
+  __syncthreads();             // the caller may still be reading the LDS it lends us
+  if (lane == 63) { s_w[wave] = ib; s_w[16 + wave] = ip; s_w[32 + wave] = is; s_w[48 + wave] = lmax; }
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    const int v = (tid >= off) ? s_sum[tid - off] : 0;
-    const int w = (tid >= off) ? s_seg[tid - off] : 0;
-    __syncthreads();
-    s_sum[tid] += v;
-    s_seg[tid] += w;
-    __syncthreads();
+  int ob = 0, op = 0, os = 0, tot_p = 0, tot_s = 0, tmax = 0;
+#pragma unroll
+  for (int w = 0; w < 16; w++) {
+    const int xb = s_w[w], xp = s_w[16 + w], xs = s_w[32 + w];
+    if (w < wave) { ob += xb; op += xp; os += xs; }
+    tot_p += xp; tot_s += xs;
+    tmax = max(tmax, s_w[48 + w]);
   }
-  int run = s_sum[tid] - local, rseg = s_seg[tid] - lseg;
+  if (nbin > 0) {   // exclusive scan of the binning blocks' pair totals
+    if (tid < nbin) P.block_prefix[tid] = ob + ib - vb;
+  } else if (tid == 0) {   // fallback path: pair_off already holds the global scan
+    P.block_prefix[0] = 0;
+  }
+  int run = op + ip - local, rseg = os + is - lseg;
   for (int i = lo; i < hi; i++) {
     const int c = __hip_atomic_load(&P.tile_count[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     P.tile_offset[i] = run;
@@ -371,16 +366,17 @@ __device__ __forceinline__ void tile_scan_body(const KP& P, int nbin, int* s_sum
     rseg += (c + kItem - 1) / kItem;
   }
   if (tid == 1023) {
-    P.tile_offset[P.T] = s_sum[1023];
-    P.seg_offset[P.T] = s_seg[1023];
-    P.counters[0] = s_sum[1023];
-    if (P.d_out) {   // all waves passed the barriers of the scan above: the maximum is complete
-      __hip_atomic_store(P.d_out + 1, s_tmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(P.d_out, s_sum[1023], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    P.tile_offset[P.T] = tot_p;
+    P.seg_offset[P.T] = tot_s;
+    P.counters[0] = tot_p;
+    if (P.d_out) {   // D and the largest tile, for the caller's capacity check / choice of sort launches
+      __hip_atomic_store(P.d_out + 1, tmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(P.d_out, tot_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    P.counters[1] = s_seg[1023];
-    if (P.d_max) atomicMax(P.d_max, s_sum[1023]);
+    P.counters[1] = tot_s;
+    if (P.d_max) atomicMax(P.d_max, tot_p);
   }
+  (void)s_seg;
 }
 
 __global__ __launch_bounds__(1024) void k_tile_scan(KP P, int nbin) {
