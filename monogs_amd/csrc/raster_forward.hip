@@ -109,7 +109,12 @@ __device__ __forceinline__ void bin_one_pair(const KP& P, int* s_tile, int emit,
 
 // project != 0 (count pass only): the projection itself runs here too - the count pass is the
 // first consumer of the records, so k_preprocess's launch and the re-read of its output go away.
-__global__ __launch_bounds__(kBinThreads) void k_bin_lds(KP P, int emit, int per_block, int project) {
+// THREADS: 1024 for large maps (a workgroup per CU), 256 for small ones (N <= kBinSmallMap: the cost
+// of these passes is then their serial floor - table init, barriers, row write - and smaller, more
+// numerous workgroups cut it: 8 k Gaussians 17.5 / 12.8 us -> see profiles/r02_forward_blend_tuning.txt).
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_bin_lds(KP P, int emit, int per_block, int project) {
+  constexpr int kBinThreads = THREADS;
   extern __shared__ int s_tile[];
   __shared__ int s_wave[kBinThreads / 64];
   int carry = 0;
@@ -1084,7 +1089,8 @@ static inline int num_cus() {
 // just above the CU count runs a second, nearly empty round: round down to a whole number of
 // rounds (300k Gaussians: 293 -> 256 workgroups of 1172).
 static inline int bin_blocks(int N) {
-  int b = max(1, min(kBinBlocks, (N + kBinThreads - 1) / kBinThreads));
+  if (N <= kBinSmallMap) return max(1, (N + 255) / 256);      // 256-thread workgroups, <= 256 of them
+  int b = max(1, min(kBinBlocks, (N + 1023) / 1024));
   const int cus = num_cus();
   if (b > cus) b = b / cus * cus;
   return b;
@@ -1102,7 +1108,10 @@ int launch_forward_project(const KP& P, hipStream_t st) {
   if (P.T <= kBinMaxTilesLds) {
     int nblk, per;
     bin_grid(P.N, nblk, per);
-    launch_smem("project_bin_count", k_bin_lds, dim3(nblk), dim3(kBinThreads), sizeof(int) * (size_t)P.T, st, P, 0, per, 1);
+    if (P.N <= kBinSmallMap)
+      launch_smem("project_bin_count", k_bin_lds<256>, dim3(nblk), dim3(256), sizeof(int) * (size_t)P.T, st, P, 0, per, 1);
+    else
+      launch_smem("project_bin_count", k_bin_lds<1024>, dim3(nblk), dim3(1024), sizeof(int) * (size_t)P.T, st, P, 0, per, 1);
     launch("bin_colsum", k_bin_colsum, dim3((P.T + 63) / 64), dim3(64 * kColGroups), st, P, nblk);   // + tile scan
   } else {
     launch("preprocess", k_preprocess, dim3((P.N + kPreBlock - 1) / kPreBlock), dim3(kPreBlock), st, P);
@@ -1122,7 +1131,10 @@ int launch_forward_blend(const KP& P, hipStream_t st) {
   if (P.T <= kBinMaxTilesLds) {
     int nblk, per;
     bin_grid(P.N, nblk, per);
-    launch_smem("bin_emit", k_bin_lds, dim3(nblk), dim3(kBinThreads), sizeof(int) * (size_t)P.T, st, P, 1, per, 0);
+    if (P.N <= kBinSmallMap)
+      launch_smem("bin_emit", k_bin_lds<256>, dim3(nblk), dim3(256), sizeof(int) * (size_t)P.T, st, P, 1, per, 0);
+    else
+      launch_smem("bin_emit", k_bin_lds<1024>, dim3(nblk), dim3(1024), sizeof(int) * (size_t)P.T, st, P, 1, per, 0);
   } else {
     if (hipMemsetAsync(P.tile_cursor, 0, sizeof(int) * (size_t)P.T, st) != hipSuccess ||
         hipMemsetAsync(P.n_touched, 0, sizeof(int) * (size_t)P.N, st) != hipSuccess)

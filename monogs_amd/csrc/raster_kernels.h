@@ -125,7 +125,7 @@ constexpr int kSeg = 64;            // splats staged at a time by the blend kern
 // that round shorter, at the price of a second per-pixel state load and checkpoint per segment.
 constexpr int kItem = 32;
 constexpr int kBinBlocks = 512;    // workgroups of the LDS-privatised binning passes
-constexpr int kBinThreads = 1024;
+constexpr int kBinSmallMap = 65536;  // up to here the binning passes run 256-thread workgroups of 256 Gaussians
 constexpr int kBinMaxTilesLds = 12288;   // T above this falls back to global atomics
 
 // Grid of the LDS-privatised binning passes (defined in raster_forward.hip): number of workgroups
