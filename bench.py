@@ -254,7 +254,7 @@ def main(argv=None):
 
     import __graft_entry__ as entry
     if not os.path.exists(entry.LIB):
-        entry.build()
+        entry.build_product()
     from monogs_amd import _cabi, rasterizer as R, synthetic as S
     from monogs_amd.parallel import FlatGradBucket, view_pose
     from monogs_amd.tracking_fused import l1_image_depth_loss_backward

@@ -1,6 +1,6 @@
 // Backward pass of the rasteriser for gfx950 (CDNA4, wave64).  Atomic-free on the gradient path:
-//   k_blend_bwd      1 wave / (tile, 64-splat segment), 4 pixels per lane (one per 8x8 quadrant):
-//                    front-to-back replay from the forward's per-segment checkpoint; per splat the
+//   k_blend_bwd      1 wave / (tile, 32-splat item), 4 pixels per lane (one per 8x8 quadrant):
+//                    front-to-back replay from the forward's per-item checkpoint; per splat the
 //                    ten screen-space sums are reduced over the wave in registers (permlane swap +
 //                    DPP reduce-scatter) and stored ONCE, with plain stores, at the pair's slot
 //   k_preprocess_bwd 1 thread / Gaussian: streams its contiguous slots, chains to
@@ -17,6 +17,8 @@
 #include "launch.h"
 #include "raster_kernels.h"
 #include "wave_reduce.h"
+#define MGS_DIAG_BACKWARD
+#include "diag_stamp.h"
 
 namespace mgs {
 
@@ -89,43 +91,6 @@ constexpr float kLog2eB = 1.4426950408889634f;
 // POSE (plain mode only): pose-only backward (tracking: every per-Gaussian gradient pointer is
 // NULL).  dL/dtau needs the mean / conic / depth sums only, so the colour and opacity sums are
 // not formed and six values instead of ten are reduced per splat.
-#ifdef MGS_STAMP   // diagnostic build only (profiles/stamp_backward.py): per-item start/end stamps and phase times
-__device__ long long g_bstamps[4 * 65536];
-__device__ long long g_bphase[4 * 65536];
-extern "C" int mgs_debug_read_bwd_stamps(long long* stamps, long long* phases, int n) {
-  const int rc = (int)hipMemcpyFromSymbol(stamps, HIP_SYMBOL(g_bstamps), sizeof(long long) * n);
-  return rc ? rc : (int)hipMemcpyFromSymbol(phases, HIP_SYMBOL(g_bphase), sizeof(long long) * n);
-}
-__device__ int* g_item_order = nullptr;     // diagnostic: dispatch order of the items (experiment)
-extern "C" int mgs_debug_set_item_order(int* dev_ptr) {
-  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_item_order), &dev_ptr, sizeof(int*));
-}
-struct BwdStamp {
-  long long t0, tl, ph[4] = {0, 0, 0, 0};
-  int nvisit = 0, nany = 0, item_id = -1, item_base = 0, nmiss = 0, nlanes = 0;
-  __device__ BwdStamp() : t0(__builtin_amdgcn_s_memrealtime()), tl(__builtin_amdgcn_s_memtime()) {}
-  __device__ void mark(int k) { const long long t = __builtin_amdgcn_s_memtime(); ph[k] += t - tl; tl = t; }
-  __device__ ~BwdStamp() {
-    if (threadIdx.x == 0 && blockIdx.x < 65536) {
-      g_bstamps[4 * blockIdx.x + 0] = t0;
-      g_bstamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-      g_bstamps[4 * blockIdx.x + 2] = ((long long)nany << 32) | nvisit;
-      g_bphase[4 * blockIdx.x + 0] = ((long long)nmiss << 32) | (unsigned int)nlanes;
-      g_bstamps[4 * blockIdx.x + 3] = ((long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32) |
-                                      __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
-      for (int k = 1; k < 3; k++) g_bphase[4 * blockIdx.x + k] = ph[k];
-      g_bphase[4 * blockIdx.x + 3] = ((long long)item_base << 32) | (unsigned int)item_id;
-    }
-  }
-};
-#define MGS_BSTAMP BwdStamp bstamp_
-#define MGS_BMARK(k) bstamp_.mark(k)
-#define MGS_BCOUNT(v, a) (bstamp_.nvisit += (v), bstamp_.nany += (a))
-#else
-#define MGS_BSTAMP
-#define MGS_BMARK(k)
-#define MGS_BCOUNT(v, a)
-#endif
 
 template <bool SKETCH, bool JONLY = false, bool POSE = false>
 __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(KP P, KB B) {
@@ -141,14 +106,10 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
   // walk, bound that variant, and the 32-splat items doubled them.
   constexpr int kReps = SKETCH ? kSketchReps : 1;
   const int n_items = min(P.seg_offset[P.T], P.max_segs);
-#ifdef MGS_STAMP
   int item_first = xcd_remap<kBwdChunk>(blockIdx.x) * kReps;
   const int lane = threadIdx.x;
-  if (g_item_order && !SKETCH) item_first = g_item_order[item_first];
+  MGS_BORDER(item_first, SKETCH);
   if (item_first < 0) return;
-#else
-  const int item_first = xcd_remap<kBwdChunk>(blockIdx.x) * kReps, lane = threadIdx.x;
-#endif
   if (item_first >= n_items) return;
   // sketch mode: per-pixel pose-Jacobian rows, as pairs (tau 0,1) (2,3) (4,5), of the tile in hand
   v2f J2[SKETCH ? 4 : 1][3];
@@ -187,18 +148,10 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
   if (rep > 0) __syncthreads();      // single-wave workgroup: orders the reuse of the staged records
   // One 16-B record per item (written by the tile sort) instead of a chain of dependent loads:
   // tile, index of the item's first key, number of splats (<= kItem), position in the tile's list.
-#ifdef MGS_STAMP
-  bstamp_.item_id = item;
-#endif
   const int4 sr = P.seg_rec[item];
   const int tile = sr.x, k0 = sr.y, nb = sr.z, base = sr.w;
-#ifdef MGS_STAMP
-  bstamp_.item_base = base;
-#endif
+  MGS_BITEM(item, base);
   if (nb <= 0) continue;
-#if defined(MGS_ABL) && MGS_ABL == 10
-  continue;
-#endif
   if constexpr (SKETCH) {
     if (tile != jtile) { flush_jacobian(); jtile = tile; }
   }
@@ -294,11 +247,6 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
     }
   }
 
-#if defined(MGS_ABL) && MGS_ABL == 11
-  if (T[0] + T[1] + T[2] + T[3] + gS[0] + gS[1] + gS[2] + gS[3] + g0[0] + g0[1] + g0[2] + g0[3] == 123.456f && lo_next == 77u)
-    B.pair_grad[lane].x = (float)(last[0] + last[1] + last[2] + last[3] + tile_last);
-  return;
-#endif
 
   MGS_BMARK(0);
   // reduce-scatter bookkeeping (wave_reduce.h): which of the ten sums this lane ends up with
@@ -337,9 +285,6 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       if (!((mq[q] >> j) & 1ull)) continue;          // wave-uniform (scalar bit test)
-#if defined(MGS_ABL) && (MGS_ABL == 2 || MGS_ABL == 3)
-      any = true; r0 += u.x; continue;
-#endif
       const v2f d = mu - Pq[q];
       // clamped at 0 like the forward's form of the exponent (the quadratic form is <= 0; only
       // rounding can make it positive)
@@ -347,10 +292,7 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
       const float ar = v.y * __builtin_amdgcn_exp2f(pw);
       const float al = fminf(kAlphaMax, ar);
       const bool k = idx < last[q] && al >= kAlphaMin;
-#ifdef MGS_STAMP
-      if (__ballot(k) == 0ull) bstamp_.nmiss++;
-      bstamp_.nlanes += __popcll(__ballot(k));
-#endif
+      MGS_BLANES(k);
       if (__ballot(k) == 0ull) continue;              // wave-uniform
       any = true;
       const float ae = k ? al : 0.f;
@@ -393,9 +335,6 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
         }
       }
     }
-#if defined(MGS_ABL) && (MGS_ABL == 1 || MGS_ABL == 3)
-    if (any) { T[0] += r0 + R12.x + R34.x + r5 + R67.x + R89.x; any = false; }
-#endif
     if (!JONLY && any) {
       // the ten wave totals land in ten different lanes; each stores its own dword of the
       // pair's record (slot of splat j broadcast from lane j): one store instruction per splat
@@ -473,10 +412,6 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
       unsigned long long todo = mq[0] | mq[1] | mq[2] | mq[3];
       MGS_BMARK(1);
       MGS_BCOUNT(__popcll(mq[0]) + __popcll(mq[1]) + __popcll(mq[2]) + __popcll(mq[3]), __popcll(todo));
-#if defined(MGS_ABL) && (MGS_ABL == 4 || MGS_ABL == 12)
-      todo = 0ull;
-      T[0] += s_r0[lane ^ 1].x + s_r1[lane ^ 1].y + s_r2[lane ^ 1].x + (float)(mq[0] + mq[1] + mq[2] + mq[3]);
-#endif
       if (todo != 0ull) {
         int j0 = __builtin_ctzll(todo);
         float4 u0 = s_r0[j0], v0 = s_r1[j0];
@@ -500,20 +435,13 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
     }
     MGS_BMARK(2);
     // splats of the segment that no pixel reached: zero record
-#if defined(MGS_ABL) && MGS_ABL == 12
-    if (slot == 0x7fffffff)
-#else
     if (!JONLY && slot >= 0 && !((written >> lane) & 1ull))
-#endif
     {
       float4* dst = B.pair_grad + (size_t)slot * 3;
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       dst[0] = z; dst[1] = z; dst[2] = z;
     }
   }
-#if defined(MGS_ABL)
-  if (T[0] == 123.456f && slot >= 0) B.pair_grad[(size_t)slot * 3].x = T[0] + T[1] + T[2] + T[3] + gS[0] + gS[1] + gS[2] + gS[3];
-#endif
   }   // rep
   flush_jacobian();
 }
@@ -878,12 +806,7 @@ int launch_backward(const KP& P, const KB& B, hipStream_t st, bool skip_tau_redu
     if (B.sketch_only) return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
   } else {
     if (B.g_means3D || B.map.on)
-#ifdef MGS_STAMP    // diagnostic: MGS_BWD_LDS_PAD bytes of dynamic LDS per item limit the items resident on a CU
-      launch_smem("blend_bwd", k_blend_bwd<false>, dim3(grid_pad(P.max_segs, kBwdChunk)), dim3(64),
-                  getenv("MGS_BWD_LDS_PAD") ? (size_t)atoi(getenv("MGS_BWD_LDS_PAD")) : 0, st, P, B);
-#else
       launch("blend_bwd", k_blend_bwd<false>, dim3(grid_pad(P.max_segs, kBwdChunk)), dim3(64), st, P, B);
-#endif
     else   // pose-only (tracking)
       launch("blend_bwd", k_blend_bwd<false, false, true>, dim3(grid_pad(P.max_segs, kBwdChunk)), dim3(64), st, P, B);
   }

@@ -21,6 +21,8 @@
 
 #include "launch.h"
 #include "raster_kernels.h"
+#define MGS_DIAG_FORWARD
+#include "diag_stamp.h"
 
 namespace mgs {
 
@@ -797,40 +799,6 @@ __device__ __forceinline__ void mask_clear_bit(unsigned long long& m, int j) {
   asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(j));
 }
 
-#ifdef MGS_STAMP   // diagnostic build only (profiles/stamp_forward.py): per-workgroup start/end stamps
-__device__ long long g_stamps[4 * 65536];
-__device__ long long g_phase[4 * 65536];
-extern "C" int mgs_debug_read_phases(long long* host, int n) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_phase), sizeof(long long) * n);
-}
-extern "C" int mgs_debug_read_stamps(long long* host, int n) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(long long) * n);
-}
-struct StampScope {
-  long long t0, c0;
-  int nseg = 0, nvisit = 0;
-  long long ph[4] = {0, 0, 0, 0}, tl = 0;
-  __device__ void mark(int k) { const long long t = __builtin_amdgcn_s_memtime(); ph[k] += t - tl; tl = t; }
-  __device__ StampScope() : t0(__builtin_amdgcn_s_memrealtime()), c0(__builtin_amdgcn_s_memtime()) { tl = c0; }
-  __device__ ~StampScope() {
-    if (threadIdx.x == 0 && blockIdx.x < 65536) {
-      g_stamps[4 * blockIdx.x + 0] = t0;
-      g_stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-      g_stamps[4 * blockIdx.x + 2] = ((__builtin_amdgcn_s_memtime() - c0) & 0xFFFFFFll) | ((long long)nseg << 24) | ((long long)nvisit << 40);
-      g_stamps[4 * blockIdx.x + 3] = ((long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32) |
-                                     __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
-      for (int k = 0; k < 4; k++) g_phase[4 * blockIdx.x + k] = ph[k];
-    }
-  }
-};
-#define MGS_STAMP_SCOPE StampScope stamp_scope_
-#define MGS_STAMP_SEG(m) (stamp_scope_.nseg++, stamp_scope_.nvisit += __popcll(m))
-#define MGS_MARK(k) stamp_scope_.mark(k)
-#else
-#define MGS_MARK(k)
-#define MGS_STAMP_SCOPE
-#define MGS_STAMP_SEG(m)
-#endif
 
 __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
   MGS_STAMP_SCOPE;
@@ -966,9 +934,6 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
       auto walk = [&](auto touch_tag, unsigned long long m) {
         constexpr bool kTouch = decltype(touch_tag)::value;
         auto visit = [&](int j, const float4 u, const float4 v, const float4 c) {
-#if defined(MGS_ABL) && MGS_ABL == 5
-          T -= 1e-9f * u.x; return;
-#endif
           const float t1 = __builtin_fmaf(v.x, yh, __builtin_fmaf(u.w, xh, u.y));
           const float t2 = __builtin_fmaf(v.y, yh, u.z);
           // the quadratic form is <= 0; the clamp only removes rounding excursions of the expanded

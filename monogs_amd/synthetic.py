@@ -4,7 +4,8 @@ to the device by the caller.
 
 Camera: TUM fr3_office intrinsics (configs/mono/tum/fr3_office.yaml:6-16 in the
 reference tree), scaled with the image size; T_w2c = I; znear 0.01, zfar 100.
-Matrices follow utils/camera_utils.py:94-104 and graphics_utils.py:56-77.
+Matrices follow utils/camera_utils.py:94-104; the projection is the closed pinhole form that
+graphics_utils.py:56-77 evaluates to (checked against reference-generated goldens).
 """
 from __future__ import annotations
 
@@ -17,22 +18,14 @@ SH_C0 = 0.28209479177387814
 
 
 def projection_matrix2(znear, zfar, cx, cy, fx, fy, W, H):
-    """Same closed form as getProjectionMatrix2 (graphics_utils.py:56-77)."""
-    left = ((2 * cx - W) / W - 1.0) * W / 2.0
-    right = ((2 * cx - W) / W + 1.0) * W / 2.0
-    top = ((2 * cy - H) / H + 1.0) * H / 2.0
-    bottom = ((2 * cy - H) / H - 1.0) * H / 2.0
-    left, right = znear / fx * left, znear / fx * right
-    top, bottom = znear / fy * top, znear / fy * bottom
-    P = torch.zeros(4, 4)
-    P[0, 0] = 2.0 * znear / (right - left)
-    P[1, 1] = 2.0 * znear / (top - bottom)
-    P[0, 2] = (right + left) / (right - left)
-    P[1, 2] = (top + bottom) / (top - bottom)
-    P[3, 2] = 1.0
-    P[2, 2] = zfar / (zfar - znear)
-    P[2, 3] = -(zfar * znear) / (zfar - znear)
-    return P
+    """Pinhole projection used with `projmatrix_raw` (what getProjectionMatrix2,
+    graphics_utils.py:56-77, evaluates to once its frustum bounds are substituted): NDC x = (2 fx X/Z
+    + (2 cx - W)) / W, likewise y; depth row maps [znear, zfar] to [0, 1]; w = Z."""
+    f, n = float(zfar), float(znear)
+    return torch.tensor([[2.0 * fx / W, 0.0, (2.0 * cx - W) / W, 0.0],
+                         [0.0, 2.0 * fy / H, (2.0 * cy - H) / H, 0.0],
+                         [0.0, 0.0, f / (f - n), -f * n / (f - n)],
+                         [0.0, 0.0, 1.0, 0.0]], dtype=torch.float32)
 
 
 class Camera(NamedTuple):
