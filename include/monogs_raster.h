@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MGS_ABI_VERSION 5
+#define MGS_ABI_VERSION 6
 
 typedef enum mgs_status {
   MGS_OK = 0,
@@ -176,9 +176,13 @@ typedef struct mgs_backward_args {
   const mgs_map_accum_args* map_accum;
   /* How the backward treats the field-of-view clamp of the EWA Jacobian, t.x = clamp(x/z) * z
    * (only splats whose centre lies outside 1.3x the field of view are affected; the forward is the
-   * same): 0 = the exact derivative of the forward (default; what the oracle's autograd gives),
-   * 1 = t.x held constant in z and its x-gradient zeroed when clamped - what the public CUDA lineage
-   * of the absent extension is believed to do (DESIGN.md §2 quantifies the difference). */
+   * same): MGS_CLAMP_GRAD_UPSTREAM = 0 (the default of a zero-initialised block) = t.x held constant
+   * in z and its x-gradient zeroed when clamped - what the public CUDA lineage of the absent
+   * extension is believed to do, i.e. the gradients the north star's tolerance refers to;
+   * MGS_CLAMP_GRAD_EXACT = 1 = the exact derivative of the forward (what plain autograd of the
+   * forward gives).  DESIGN.md §2 quantifies the difference.  (ABI 5 had the two values swapped.) */
+#define MGS_CLAMP_GRAD_UPSTREAM 0
+#define MGS_CLAMP_GRAD_EXACT 1
   int32_t clamp_gradient_mode;
   int32_t reserved0;
 } mgs_backward_args;

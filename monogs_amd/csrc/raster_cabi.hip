@@ -92,7 +92,7 @@ int fill_kp(const mgs_forward_args& a, bool need_bins, bool need_outputs, KP& P)
   if (P.T <= kBinMaxTilesLds) { int nblk; bin_grid(P.N, nblk, P.per_block); }
   else P.per_block = 0x7fffffff;
   P.big_pass = a.big_tile_pass < 0 ? 0 : 1;
-  P.clamp_up = 0;
+  P.clamp_up = 1;
   return MGS_OK;
 }
 
@@ -176,7 +176,7 @@ static int32_t raster_backward_impl(const mgs_backward_args* args, void* stream,
   if (rc != MGS_OK) return rc;
   if (!args->grad_color || !args->bwd || !args->grad_tau) return MGS_ERR_BAD_ARGUMENT;
   if (args->clamp_gradient_mode != 0 && args->clamp_gradient_mode != 1) return MGS_ERR_BAD_ARGUMENT;
-  P.clamp_up = args->clamp_gradient_mode;
+  P.clamp_up = args->clamp_gradient_mode == MGS_CLAMP_GRAD_UPSTREAM;
   {   // per-Gaussian gradients: all of the mandatory four, or none at all (pose-only / mapping mode)
     const int have = (args->grad_means3D != nullptr) + (args->grad_means2D != nullptr) +
                      (args->grad_colors != nullptr) + (args->grad_opacities != nullptr);

@@ -93,9 +93,9 @@ def _gauss_window(size: int, sigma: float, channels: int, like: torch.Tensor) ->
     return w.expand(channels, 1, size, size).contiguous().to(like)
 
 
-def ssim(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11, size_average: bool = True):
-    """loss_utils.py:63-96: mean SSIM with an 11x11 Gaussian window (sigma 1.5), zero padding,
-    C1 = 0.01^2, C2 = 0.03^2; inputs [B,C,H,W] (or [C,H,W]) in [0, 1]."""
+def ssim_map(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11) -> torch.Tensor:
+    """Per-pixel SSIM index [B,C,H,W] (loss_utils.py:61-101, `_ssim` before its mean): 11x11
+    Gaussian window (sigma 1.5) applied per channel with ZERO padding, C1 = 0.01^2, C2 = 0.03^2."""
     if img1.dim() == 3:
         img1, img2 = img1.unsqueeze(0), img2.unsqueeze(0)
     ch = img1.shape[-3]
@@ -107,7 +107,13 @@ def ssim(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11, size_ave
     s22 = F.conv2d(img2 * img2, w, padding=pad, groups=ch) - mu2 * mu2
     s12 = F.conv2d(img1 * img2, w, padding=pad, groups=ch) - mu1 * mu2
     C1, C2 = 0.01 ** 2, 0.03 ** 2
-    m = ((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 * mu1 + mu2 * mu2 + C1) * (s11 + s22 + C2))
+    return ((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 * mu1 + mu2 * mu2 + C1) * (s11 + s22 + C2))
+
+
+def ssim(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11, size_average: bool = True):
+    """loss_utils.py:63-96: mean of `ssim_map` over everything, or per batch row; inputs
+    [B,C,H,W] (or [C,H,W]) in [0, 1]."""
+    m = ssim_map(img1, img2, window_size)
     return m.mean() if size_average else m.mean(1).mean(1).mean(1)
 
 

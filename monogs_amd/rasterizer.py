@@ -38,10 +38,11 @@ class GaussianRasterizationSettings(NamedTuple):
 # pair-capacity high-water mark per device: the blend stage is launched optimistically
 # with this capacity while the host waits (concurrently) for the true pair count.
 # Backward treatment of the EWA field-of-view clamp (include/monogs_raster.h: clamp_gradient_mode):
-# "exact" (default) or "upstream" (stop-gradient through the clamp, as the absent CUDA extension is
-# believed to behave).  Only splats centred outside 1.3x the field of view are affected.
-CLAMP_GRADIENT_MODES = {"exact": 0, "upstream": 1}
-_clamp_gradient_mode = 0
+# "upstream" (default: stop-gradient through the clamp, as the absent CUDA extension is believed to
+# behave - the gradients the north star's tolerance is stated against) or "exact" (the derivative of
+# the forward as autograd would give it).  Only splats centred outside 1.3x the field of view differ.
+CLAMP_GRADIENT_MODES = {"upstream": 0, "exact": 1}
+_clamp_gradient_mode = CLAMP_GRADIENT_MODES["upstream"]
 
 
 def set_clamp_gradient_mode(mode: str) -> None:

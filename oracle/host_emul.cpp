@@ -45,7 +45,7 @@ Camera make_camera(const float* V, const float* PM, const float* Praw, const flo
   c.focal_x = W / (2.0f * tanfovx); c.focal_y = H / (2.0f * tanfovy);
   c.scale_modifier = scale_modifier; c.sh_degree = sh_degree; c.sh_coeffs = sh_coeffs;
   c.grid_x = (W + kTile - 1) / kTile; c.grid_y = (H + kTile - 1) / kTile;
-  c.clamp_grad_upstream = 0;
+  c.clamp_grad_upstream = 1;
   return c;
 }
 

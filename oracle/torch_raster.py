@@ -195,7 +195,7 @@ class Projected(NamedTuple):
 
 def project(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
             cov3D_precomp, settings: RasterSettings, tau: Optional[torch.Tensor],
-            clamp_grad: str = "exact"):
+            clamp_grad: str = "upstream"):
     """Per-Gaussian projection + EWA splat (contract rows a4).
 
     clamp_grad selects how the backward treats the field-of-view clamp of the EWA Jacobian,
@@ -387,7 +387,7 @@ def composite(proj: Projected, settings: RasterSettings):
 
 
 def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-              cov3D_precomp, settings: RasterSettings, theta=None, rho=None, clamp_grad: str = "exact"):
+              cov3D_precomp, settings: RasterSettings, theta=None, rho=None, clamp_grad: str = "upstream"):
     """Oracle of `GaussianRasterizer.forward` (gaussian_renderer/__init__.py:151-168).
     Returns (image, radii, depth, opacity, n_touched) plus an `info` dict."""
     tau = None

@@ -66,18 +66,32 @@ def test_psnr_matches_the_reference_helper_and_ssim_properties():
     s_ab = E.ssim(a, b).item()
     assert 0.3 < s_ab < 1.0 and abs(s_ab - E.ssim(b, a).item()) < 1e-6
     assert E.ssim(a, b, size_average=False).shape == (2,)
-    # direct evaluation of the definition at one interior pixel
+    # The definition (ref gaussian_splatting/utils/loss_utils.py:61-101 - pure torch, but the module
+    # imports cv2, so it is restated here rather than imported) evaluated by hand at an interior
+    # pixel and at two border pixels, where the window hangs over the ZERO padding.
     img1, img2 = a[:1, :1], b[:1, :1]
+    H, W = img1.shape[-2:]
     w = E._gauss_window(11, 1.5, 1, img1)[0, 0]
-    p1, p2 = img1[0, 0, 5:16, 8:19], img2[0, 0, 5:16, 8:19]
-    mu1, mu2 = (w * p1).sum(), (w * p2).sum()
-    s11, s22, s12 = (w * p1 * p1).sum() - mu1 ** 2, (w * p2 * p2).sum() - mu2 ** 2, (w * p1 * p2).sum() - mu1 * mu2
-    want = ((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 ** 2 + mu2 ** 2 + 1e-4) * (s11 + s22 + 9e-4))
-    from torch.nn import functional as F
-    full = E.ssim(img1, img2, size_average=False)
-    mu_map = F.conv2d(img1, E._gauss_window(11, 1.5, 1, img1), padding=5)
-    assert torch.allclose(mu_map[0, 0, 10, 13], mu1, atol=1e-6)
-    assert full.shape == (1,) and torch.isfinite(want)
+    smap = E.ssim_map(img1, img2)
+    assert smap.shape == img1.shape
+
+    def by_hand(y, x):
+        p1, p2 = torch.zeros(11, 11), torch.zeros(11, 11)
+        for dy in range(11):
+            for dx in range(11):
+                yy, xx = y + dy - 5, x + dx - 5
+                if 0 <= yy < H and 0 <= xx < W:
+                    p1[dy, dx], p2[dy, dx] = img1[0, 0, yy, xx], img2[0, 0, yy, xx]
+        mu1, mu2 = (w * p1).sum(), (w * p2).sum()
+        s11, s22 = (w * p1 * p1).sum() - mu1 ** 2, (w * p2 * p2).sum() - mu2 ** 2
+        s12 = (w * p1 * p2).sum() - mu1 * mu2
+        return ((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 ** 2 + mu2 ** 2 + 1e-4) * (s11 + s22 + 9e-4))
+
+    for (y, x) in ((10, 13), (0, 0), (H - 1, 3)):
+        want = by_hand(y, x)
+        assert torch.isfinite(want) and abs(smap[0, 0, y, x].item() - want.item()) < 2e-5, (y, x)
+    assert abs(E.ssim(img1, img2).item() - smap.mean().item()) < 1e-7
+    assert torch.allclose(E.ssim(a, b, size_average=False), E.ssim_map(a, b).reshape(2, -1).mean(1), atol=1e-6)
 
 
 def test_tum_sequence_reader(tmp_path):

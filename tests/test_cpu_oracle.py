@@ -238,7 +238,7 @@ def test_oracle_pose_gradient_matches_finite_differences():
 
     theta = torch.zeros(3, dtype=torch.float64, requires_grad=True)
     rho = torch.zeros(3, dtype=torch.float64, requires_grad=True)
-    img, _, dep, _, _, _ = O.rasterize(m, None, sh, None, o, s, r, None, st, theta, rho)
+    img, _, dep, _, _, _ = O.rasterize(m, None, sh, None, o, s, r, None, st, theta, rho, clamp_grad="exact")
     ((img * gi).sum() + (dep * gd).sum()).backward()
     ana = torch.cat([rho.grad, theta.grad])
     eps = 1e-6
@@ -257,7 +257,7 @@ def test_oracle_parameter_gradients_match_finite_differences():
     gi = torch.randn(3, 16, 16, generator=torch.Generator().manual_seed(5), dtype=torch.float64)
 
     def f(m_, s_, r_, o_, sh_):
-        img, _, dep, _, _, _ = O.rasterize(m_, None, sh_, None, o_, s_, r_, None, st)
+        img, _, dep, _, _, _ = O.rasterize(m_, None, sh_, None, o_, s_, r_, None, st, clamp_grad="exact")
         return (img * gi).sum() + 0.3 * dep.sum()
 
     leaves = [t.clone().requires_grad_() for t in (m, s, r, o, sh)]

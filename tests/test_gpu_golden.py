@@ -73,6 +73,60 @@ def test_hip_matches_the_crowded_mid_size_vectors(built):
     _check(want, *out)
 
 
+def _check_full(want, img, dep, opa, radii, nt, g=None):
+    """Against the thinned full-size vectors of tests/golden/make_full_golden.py: images at every
+    `pix_step`-th row / column plus whole-image mean and L1 mass, per-Gaussian arrays at every
+    `g_step`-th Gaussian plus whole-array norms / sums."""
+    ps, gs = int(want["pix_step"]), int(want["g_step"])
+    for name, a, tol in (("image", img, FWD_L1), ("depth", dep, 1e-3), ("opacity", opa, FWD_L1)):
+        a = a.detach().cpu()
+        sub = torch.from_numpy(want[name + "_sub"])
+        assert (a[:, ::ps, ::ps] - sub).abs().mean().item() <= tol, name
+        assert abs(a.double().mean().item() - float(want[name + "_mean"])) <= tol, name
+        assert abs(a.double().abs().sum().item() - float(want[name + "_l1"])) <= tol * a.numel(), name
+    r = radii.cpu()
+    assert (r[::gs] != torch.from_numpy(want["radii_thin"])).float().mean().item() <= 1e-3
+    assert abs(int(r.long().sum()) - int(want["radii_sum"])) <= 1e-4 * int(want["radii_sum"])
+    ntw = torch.from_numpy(want["n_touched_thin"])
+    assert (nt.cpu()[::gs] - ntw).abs().sum().item() <= 0.002 * ntw.sum().item() + 5
+    assert abs(int(nt.long().sum()) - int(want["n_touched_sum"])) <= 0.002 * int(want["n_touched_sum"])
+    if g is None:
+        return
+    for k, v in g.items():
+        tol = 2e-3 if k == "grad_tau" else BWD_REL
+        if k == "grad_tau":
+            e = rel_err(v, torch.from_numpy(want[k]))
+        else:
+            e = rel_err(v[::gs], torch.from_numpy(want[k + "_thin"]))
+            n = float(want[k + "_norm"])
+            assert abs(float(v.double().norm()) - n) <= tol * n, k
+        assert e <= tol, (k, e)
+
+
+def test_hip_matches_the_full_size_oracle_vectors_syn_b(built):
+    """BASELINE config 2: 100 000 Gaussians @ 640x480, forward, against the torch oracle's committed
+    (thinned) outputs - evidence at the configured size that does not share csrc/raster_math.h."""
+    from monogs_amd import rasterizer as R
+    from monogs_amd import synthetic as S
+    want = np.load(os.path.join(GOLD, "syn_b_oracle.npz"))
+    img, dep, opa, radii, nt, _ = _hip(S.make_scene(100000, 640, 480, seed=0))
+    assert R.last_stats["pairs"] <= int(want["pairs"])
+    assert int((radii > 0).sum()) == int(want["n_visible"])
+    _check_full(want, img, dep, opa, radii, nt)
+
+
+def test_hip_matches_the_full_size_oracle_vectors_syn_c(built):
+    """BASELINE config 3 (the workload bench.py times): 300 000 Gaussians @ 640x480, forward and
+    every gradient sink incl. dL/dtau, against the torch oracle's committed (thinned) outputs."""
+    from monogs_amd import rasterizer as R
+    from monogs_amd import synthetic as S
+    want = np.load(os.path.join(GOLD, "syn_c_oracle.npz"))
+    img, dep, opa, radii, nt, g = _hip(S.make_scene(300000, 640, 480, seed=0))
+    assert R.last_stats["pairs"] <= int(want["pairs"])
+    assert int((radii > 0).sum()) == int(want["n_visible"])
+    _check_full(want, img, dep, opa, radii, nt, g)
+
+
 def test_hip_matches_the_sh3_vectors(built):
     want = np.load(os.path.join(GOLD, "sh3.npz"))
     sc, shs, campos = scenes.sh3_inputs()
@@ -80,12 +134,13 @@ def test_hip_matches_the_sh3_vectors(built):
 
 
 def test_clamp_gradient_modes_match_their_oracle_variants(built):
-    """mgs_backward_args.clamp_gradient_mode: 0 = exact derivative (default), 1 = the treatment the
-    absent CUDA extension is believed to use; each against the matching oracle variant on a scene
+    """mgs_backward_args.clamp_gradient_mode: 0 = the treatment the absent CUDA extension is believed
+    to use (default), 1 = exact derivative; each against the matching oracle variant on a scene
     with hundreds of visible splats beyond 1.3x the field of view."""
     from monogs_amd import rasterizer as R
     want = np.load(os.path.join(GOLD, "wide_clamp.npz"))
     sc = scenes.wide_scene()
+    assert R._clamp_gradient_mode == R.CLAMP_GRADIENT_MODES["upstream"]      # the product default
     try:
         for mode in ("exact", "upstream"):
             R.set_clamp_gradient_mode(mode)
@@ -99,7 +154,7 @@ def test_clamp_gradient_modes_match_their_oracle_variants(built):
             # ... and NOT the other one: the two differ by ~1.6 % here
             assert rel_err(g["grad_means3D"], torch.from_numpy(want[f"grad_means3D_{other}"])) > 5e-3
     finally:
-        R.set_clamp_gradient_mode("exact")
+        R.set_clamp_gradient_mode("upstream")
 
 
 def test_sketch_kat(built):
