@@ -277,8 +277,22 @@ typedef struct mgs_pose_adam_args {
    * loss and 1 / loss to loss_view[0], loss_view[1]. */
   const float* loss_grad_out;
   int32_t loss_norm_mode;
+  /* != 0: once *converged is set the kernel does nothing at all (no step, no best-iterate update):
+   * the reference leaves its loop at the first converged iteration (utils/slam_frontend.py:623-626);
+   * a caller that reads the flag only every few iterations gets the same result. */
+  int32_t sticky_converged;
+  /* Best-iterate bookkeeping of the tracking loop (utils/slam_frontend.py:423-425, 510, 523-528):
+   * l1_partials = [n] block sums of |residual| (UN-Hubered, the reference's
+   * loss_tracking_scalar = ||loss_tracking_img||_1) of the render this iteration started from;
+   * when their sum is below best[0] the state that was rendered (T, exposure_a, exposure_b BEFORE
+   * this step - what TempCamera(viewpoint) copies) is stored: best = float[MGS_TRACK_BEST_FLOATS]
+   * {best L1 (caller sets +inf), T[16], a, b, index of the best iteration, iteration counter}. */
+  const float* l1_partials;
+  float* best;
+  int32_t num_l1_partials;
   int32_t reserved0;
 } mgs_pose_adam_args;
+#define MGS_TRACK_BEST_FLOATS 24
 
 int32_t mgs_pose_adam_step(const mgs_pose_adam_args* args, void* stream);
 
@@ -345,6 +359,12 @@ typedef struct mgs_lm_step_args {
   const float* loss;         /* [1] current ||residual||_1 (lm_state only) */
   float increase_factor, decrease_factor, min_lambda, max_lambda;
   float converged_threshold; /* lm_state[3] = |x| < threshold (slam_frontend.py:699) */
+  /* With lm_state: a converged step is NOT applied and every later call is a no-op (the reference
+   * breaks before new_viewpoint_params is ever assigned, slam_frontend.py:699-706).
+   * best (or NULL): same float[MGS_TRACK_BEST_FLOATS] block as mgs_pose_adam_args.best; *loss is the
+   * criterion, the pose / exposure this iteration rendered (before the step) is what is stored. */
+  int32_t reserved0;
+  float* best;
 } mgs_lm_step_args;
 
 int32_t mgs_lm_solve_step(const mgs_lm_step_args* args, void* stream);
@@ -353,7 +373,8 @@ int32_t mgs_lm_solve_step(const mgs_lm_step_args* args, void* stream);
  * utils/slam_frontend.py:596-598):
  *   loss = || Huber_delta( opacity * mask * ((|a| + eps) * image + b - gt) ) ||_2
  * huber_delta <= 0 disables Huber.  `partial` holds mgs_tracking_loss_partial_count floats
- * (three per reduction block: forward sums, then the two exposure-gradient sums),
+ * (four per reduction block: forward sums, the two exposure-gradient sums, and - onepass only -
+ * the block sums of |residual| before Huber),
  * `scalars` 2 floats ([0] = loss, [1] = 1/loss) written by forward and read by backward. */
 typedef struct mgs_tracking_loss_args {
   const float* image;          /* [3,H,W] */
@@ -385,7 +406,8 @@ int32_t mgs_tracking_loss_fused(const mgs_tracking_loss_args* args, int32_t* num
 /* ONE launch: block sums of the squared residuals ([n] at partial), UN-normalised image gradient
  * (as if loss were 1) and un-normalised exposure partials ([2,n] at partial + n).  The consumer
  * (mgs_pose_adam_step with loss_norm_mode = 1) applies grad_out / loss.  args->scalars is not
- * written here.  Replaces the two launches of mgs_tracking_loss_fused inside
+ * written here.  partial + 3n: [n] block sums of |residual| BEFORE Huber (the best-iterate criterion
+ * of utils/slam_frontend.py:510).  Replaces the two launches of mgs_tracking_loss_fused inside
  * mgs_tracking_iteration (reference: utils/slam_utils.py:188-217 get_loss_tracking_rgb + autograd). */
 int32_t mgs_tracking_loss_onepass(const mgs_tracking_loss_args* args, int32_t* num_blocks_out, void* stream);
 
@@ -421,6 +443,9 @@ typedef struct mgs_tracking_iter_args {
   mgs_pose_adam_args adam;       /* grad_* fields are filled in by the call; T must be set */
   int32_t camera_matrices_valid; /* != 0: fwd.viewmatrix / projmatrix already match T (every
                                     mgs_tracking_iteration leaves them so): skip that launch */
+  int32_t reserved0;
+  float* best;                /* float[MGS_TRACK_BEST_FLOATS] best-iterate block (see mgs_pose_adam_args), or
+                                 NULL; shared by the first- and second-order iterations of a frame */
 } mgs_tracking_iter_args;
 
 int32_t mgs_tracking_iteration(const mgs_tracking_iter_args* args, void* stream);

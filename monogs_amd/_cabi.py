@@ -82,7 +82,11 @@ class PoseAdamArgs(C.Structure):
            ("projmatrix_out", _fp), ("no_pose_update", C.c_int32), ("loss_partials", _fp),
            ("num_loss_partials", C.c_int32), ("loss_w_rgb", C.c_float), ("loss_w_depth", C.c_float),
            ("loss_view", _fp), ("loss_accum", _fp), ("loss_grad_out", _fp),
-           ("loss_norm_mode", C.c_int32), ("reserved0", C.c_int32)])
+           ("loss_norm_mode", C.c_int32), ("sticky_converged", C.c_int32), ("l1_partials", _fp),
+           ("best", _fp), ("num_l1_partials", C.c_int32), ("reserved0", C.c_int32)])
+
+
+TRACK_BEST_FLOATS = 24     # MGS_TRACK_BEST_FLOATS: {best L1, T[16], a, b, index of the best iteration, counter}
 
 
 class MappingLossArgs(C.Structure):
@@ -100,7 +104,8 @@ class LMStepArgs(C.Structure):
                 ("exposure_a", _fp), ("exposure_b", _fp), ("x_out", _fp),
                 ("sj_tau", _fp), ("sj_exposure", _fp), ("lm_state", _fp), ("loss", _fp),
                 ("increase_factor", C.c_float), ("decrease_factor", C.c_float),
-                ("min_lambda", C.c_float), ("max_lambda", C.c_float), ("converged_threshold", C.c_float)]
+                ("min_lambda", C.c_float), ("max_lambda", C.c_float), ("converged_threshold", C.c_float),
+                ("reserved0", C.c_int32), ("best", _fp)]
 
 
 class TrackingLossArgs(C.Structure):
@@ -112,7 +117,8 @@ class TrackingLossArgs(C.Structure):
 class TrackingIterArgs(C.Structure):
     _fields_ = [("fwd", ForwardArgs), ("bwd", _fp), ("grad_image", _fp), ("grad_tau", _fp),
                 ("grad_exposure", _fp), ("one", _fp), ("loss", TrackingLossArgs),
-                ("adam", PoseAdamArgs), ("camera_matrices_valid", C.c_int32)]
+                ("adam", PoseAdamArgs), ("camera_matrices_valid", C.c_int32), ("reserved0", C.c_int32),
+                ("best", _fp)]
 
 
 class SketchResidualArgs(C.Structure):

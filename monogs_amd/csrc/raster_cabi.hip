@@ -275,6 +275,7 @@ int32_t mgs_tracking_iteration(const mgs_tracking_iter_args* args, void* stream)
   A.loss_partials = L.partial; A.num_loss_partials = nblk;
   A.loss_norm_mode = 1; A.loss_grad_out = args->one;
   A.loss_view = L.scalars; A.loss_accum = nullptr;
+  A.best = args->best; A.l1_partials = L.partial + 3 * (size_t)nblk; A.num_l1_partials = nblk;
   A.projection = args->fwd.projmatrix_raw;
   A.viewmatrix_out = const_cast<float*>(args->fwd.viewmatrix);
   A.projmatrix_out = const_cast<float*>(args->fwd.projmatrix);
@@ -381,6 +382,7 @@ int32_t mgs_tracking_iteration_second_order(const mgs_tracking_so_args* args, vo
   mgs_lm_step_args L = args->lm;
   L.SJ = nullptr; L.sj_tau = sj_tau; L.sj_exposure = sj_exp; L.Sf = Sf; L.rows = d; L.loss = l1;
   L.T = b.adam.T; L.exposure_a = b.adam.exposure_a; L.exposure_b = b.adam.exposure_b;
+  L.best = b.best;
   return mgs_lm_solve_step(&L, stream);
 }
 

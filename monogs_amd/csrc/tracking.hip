@@ -67,8 +67,17 @@ __global__ __launch_bounds__(512) void k_pose_adam_update(mgs_pose_adam_args A) 
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     if (lane == 0) s_loss[c] = v;
   }
+  __shared__ float s_l1;
+  if (A.l1_partials && A.best && wave == 5) {       // (wave 5 has also summed a tau component: both are short)
+    float v = 0.f;
+#pragma unroll 8
+    for (int i = lane; i < A.num_l1_partials; i += 64) v += A.l1_partials[i];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if (lane == 0) s_l1 = v;
+  }
   __syncthreads();
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (A.sticky_converged && A.converged && *A.converged != 0) return;    // the reference has left its loop
   float grad_scale = 1.f;
   if (A.loss_partials && A.loss_norm_mode == 1) {
     // tracking objective = sqrt(sum h^2): the gradients summed above lack its 1 / loss
@@ -110,6 +119,14 @@ __global__ __launch_bounds__(512) void k_pose_adam_update(mgs_pose_adam_args A) 
     Tm[i] = have_T ? A.T[i] : 0.f;
     proj[i] = want_mats ? A.projection[i] : 0.f;
   }
+  // best-iterate snapshot: the state this iteration RENDERED (before the step below)
+  float best_prev = 0.f, best_count = 0.f;
+  if (A.best) { best_prev = A.best[0]; best_count = A.best[20]; }
+  const bool improved = A.best && A.l1_partials && have_T && s_l1 < best_prev;
+  float snap[18];
+#pragma unroll
+  for (int i = 0; i < 16; i++) snap[i] = Tm[i];
+  snap[16] = p[6]; snap[17] = p[7];
   const float bc1 = 1.f - powf(A.beta1, (float)A.step);
   const float bc2s = sqrtf(1.f - powf(A.beta2, (float)A.step));
 #pragma unroll
@@ -149,6 +166,15 @@ __global__ __launch_bounds__(512) void k_pose_adam_update(mgs_pose_adam_args A) 
       if (on[o]) { A.exp_avg[o] = m[o]; A.exp_avg_sq[o] = v[o]; }
       if (on[o] || (move && o < 6)) P[g][i] = p[o];     // applied deltas are zeroed even without a step
     }
+  if (A.best) {
+    if (improved) {
+      A.best[0] = s_l1;
+#pragma unroll
+      for (int i = 0; i < 18; i++) A.best[1 + i] = snap[i];
+      A.best[19] = best_count;
+    }
+    A.best[20] = best_count + 1.f;
+  }
   if (have_T) {
     if (move) for (int i = 0; i < 12; i++) A.T[i] = Tm[i];
     const float n2 = th[0] * th[0] + th[1] * th[1] + th[2] * th[2] + rho[0] * rho[0] + rho[1] * rho[1] +
@@ -287,21 +313,23 @@ __global__ __launch_bounds__(kLossBlock) void k_track_loss_bwd_finish(mgs_tracki
 
 // One pass (mgs_tracking_loss_onepass): block sums of h^2, the image gradient and the exposure
 // partials WITHOUT the 1 / loss factor of the norm's derivative; k_pose_adam_update applies it
-// (loss_norm_mode).  partial = [n] sum h^2 | [n] d/da | [n] d/db.
+// (loss_norm_mode).  partial = [n] sum h^2 | [n] d/da | [n] d/db | [n] sum |r| (before Huber).
 __global__ __launch_bounds__(kLossBlock) void k_track_loss_onepass(mgs_tracking_loss_args A) {
   __shared__ float s_red[kLossBlock / 64];
   const float a = A.exposure_a[0];
   const float gain = fabsf(a) + A.exposure_eps, bias = A.exposure_b[0];
   const float sgn = a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f);
   const size_t HW = (size_t)A.num_pixels;
-  float acc = 0.f, ga = 0.f, gb = 0.f;
+  float acc = 0.f, ga = 0.f, gb = 0.f, l1 = 0.f;
   for (size_t p = (size_t)blockIdx.x * kLossBlock + threadIdx.x; p < HW; p += (size_t)gridDim.x * kLossBlock) {
     const float om = A.opacity[p] * (A.mask ? A.mask[p] : 1.f);
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       const float im = A.image[c * HW + p];
       float dh;
-      const float h = huber(om * (gain * im + bias - A.gt[c * HW + p]), A.huber_delta, dh);
+      const float r = om * (gain * im + bias - A.gt[c * HW + p]);
+      l1 += fabsf(r);
+      const float h = huber(r, A.huber_delta, dh);
       acc += h * h;
       const float gr = h * dh * om;
       A.grad_image[c * HW + p] = gr * gain;
@@ -312,10 +340,12 @@ __global__ __launch_bounds__(kLossBlock) void k_track_loss_onepass(mgs_tracking_
   const float t = block_sum(acc, s_red);
   const float ta = block_sum(ga, s_red);
   const float tb = block_sum(gb, s_red);
+  const float tl = block_sum(l1, s_red);
   if (threadIdx.x == 0) {
     A.partial[blockIdx.x] = t;
     A.partial[gridDim.x + blockIdx.x] = ta * sgn;
     A.partial[2 * gridDim.x + blockIdx.x] = tb;
+    A.partial[3 * gridDim.x + blockIdx.x] = tl;
   }
 }
 
@@ -359,6 +389,7 @@ __global__ __launch_bounds__(256) void k_lm_solve_step(mgs_lm_step_args A) {
   }
   __syncthreads();
   if (threadIdx.x != 0) return;
+  if (A.lm_state && A.lm_state[3] != 0.f) return;      // converged earlier: the reference has left its loop
   double H[8][8], g[8];
   int k = 0;
   for (int i = 0; i < 8; i++)
@@ -400,11 +431,25 @@ __global__ __launch_bounds__(256) void k_lm_solve_step(mgs_lm_step_args A) {
     x[i] = sum / L[i][i];
   }
   for (int i = 0; i < 8; i++) A.x_out[i] = (float)x[i];
+  bool converged = false;
   if (A.lm_state) {
     double n2 = 0.0;
     for (int i = 0; i < 8; i++) n2 += x[i] * x[i];
-    A.lm_state[3] = sqrt(n2) < (double)A.converged_threshold ? 1.f : 0.f;
+    converged = sqrt(n2) < (double)A.converged_threshold;
+    A.lm_state[3] = converged ? 1.f : 0.f;
   }
+  if (A.best && A.loss && A.T) {     // best iterate = the state this iteration rendered (before the step)
+    const float count = A.best[20];
+    if (A.loss[0] < A.best[0]) {
+      A.best[0] = A.loss[0];
+      for (int i = 0; i < 16; i++) A.best[1 + i] = A.T[i];
+      A.best[17] = A.exposure_a ? A.exposure_a[0] : 0.f;
+      A.best[18] = A.exposure_b ? A.exposure_b[0] : 0.f;
+      A.best[19] = count;
+    }
+    A.best[20] = count + 1.f;
+  }
+  if (converged) return;             // slam_frontend.py:699-706: the converged step is never assigned
   if (A.T) {
     const float rho[3] = {(float)x[0], (float)x[1], (float)x[2]};
     const float th[3] = {(float)x[3], (float)x[4], (float)x[5]};
@@ -815,7 +860,7 @@ int32_t mgs_sketch_residual(const mgs_sketch_residual_args* a, void* stream) {
   return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
-int32_t mgs_tracking_loss_partial_count(int64_t num_pixels) { return 3 * loss_blocks(num_pixels); }
+int32_t mgs_tracking_loss_partial_count(int64_t num_pixels) { return 4 * loss_blocks(num_pixels); }
 
 // Fused form used by mgs_tracking_iteration: forward sums + backward in two launches; the
 // exposure partials ([2, nblk]) start at partial + nblk.

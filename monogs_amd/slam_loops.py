@@ -106,6 +106,8 @@ def tracking_step_first_order(viewpoint, gaussians, pose_optimizer, background, 
     render_pkg = render(viewpoint, gaussians, pipe, background)
     res = get_loss_tracking_per_pixel(config, render_pkg["render"], render_pkg["depth"],
                                       render_pkg["opacity"], viewpoint)
+    # the reference's best-iterate criterion: ||residual||_1 before Huber (slam_frontend.py:510)
+    render_pkg["tracking_l1"] = res.detach().abs().sum()
     rgn = config["Training"]["RGN"]
     if rgn["use_huber"]:
         res = HuberLoss.apply(res, rgn["huber_delta"])
@@ -126,6 +128,9 @@ def tracking_step_first_order_fused(viewpoint, gaussians, fused_optimizer, backg
     from .tracking_fused import tracking_loss
     render_pkg = render(viewpoint, gaussians, pipe, background)
     rgn = config["Training"]["RGN"]
+    with torch.no_grad():
+        render_pkg["tracking_l1"] = get_loss_tracking_per_pixel(
+            config, render_pkg["render"], render_pkg["depth"], render_pkg["opacity"], viewpoint).abs().sum()
     loss = tracking_loss(render_pkg["render"], render_pkg["opacity"], viewpoint,
                          rgn["huber_delta"] if rgn["use_huber"] else 0.0)
     fused_optimizer.zero_grad()
@@ -189,11 +194,13 @@ def sketch_args_from_buckets(bucket: torch.Tensor, weights: torch.Tensor, height
 
 def tracking_step_second_order(viewpoint, gaussians, background, lambda_, repeat_dim=1,
                                stack_dim=16, sketch_dim=64, pipe=Pipe, config=DEFAULT_CONFIG,
-                               generator=None, fused_solve=False, fsa=None):
+                               generator=None, fused_solve=False, fsa=None, return_pkg=False):
     """One sketched Levenberg-Marquardt iteration (slam_frontend.py:484-710): sketched
     render, bucket-summed residual Sf, `repeat_dim` backward passes harvesting the sketched
     Jacobian SJ[(repeat*stack*sketch), 8], damped least squares, left-multiplicative pose
-    step and exposure step."""
+    step and exposure step.  `lambda_` is the damping, or a callable that maps this render's L1
+    residual (the reference's loss_tracking_scalar) to it - the trust-region rule of :536-545 needs
+    the current loss before the solve.  Returns (l1, x, SJ, Sf[, render_pkg])."""
     H, W = viewpoint.image_height, viewpoint.image_width
     m, dper = H * W, stack_dim * sketch_dim
     if fsa is None:
@@ -202,6 +209,9 @@ def tracking_step_second_order(viewpoint, gaussians, background, lambda_, repeat
     render_pkg = render(viewpoint, gaussians, pipe, background, forward_sketch_args=fsa)
     res = get_loss_tracking_per_pixel(config, render_pkg["render"], render_pkg["depth"],
                                       render_pkg["opacity"], viewpoint, forward_sketch_args=fsa)
+    l1 = res.detach().abs().sum()      # loss_tracking_scalar (slam_frontend.py:510): before Huber
+    if callable(lambda_):
+        lambda_ = lambda_(l1)
     rgn = config["Training"]["RGN"]
     if rgn["use_huber"]:
         res = HuberLoss.apply(res, rgn["huber_delta"])
@@ -224,7 +234,7 @@ def tracking_step_second_order(viewpoint, gaussians, background, lambda_, repeat
             SJ = SJ.reshape(-1, n)
             Sf = Sf.flatten()
             x = lm_solve_step(SJ, Sf, lambda_, viewpoint)
-        return weighted.detach().abs().sum(), x, SJ, Sf
+        return (l1, x, SJ, Sf, render_pkg) if return_pkg else (l1, x, SJ, Sf)
     with torch.no_grad():
         SJ = SJ.reshape(-1, n)
         Sf = Sf.flatten()
@@ -235,7 +245,89 @@ def tracking_step_second_order(viewpoint, gaussians, background, lambda_, repeat
         viewpoint.T.copy_(SE3_exp(x[:6]) @ viewpoint.T)
         viewpoint.exposure_a += x[6]
         viewpoint.exposure_b += x[7]
-    return weighted.detach().abs().sum(), x, SJ, Sf
+    return (l1, x, SJ, Sf, render_pkg) if return_pkg else (l1, x, SJ, Sf)
+
+
+class TempCamera:
+    """Copy of the per-frame state the tracking loop snapshots and restores
+    (slam_frontend.py:28-53)."""
+
+    def __init__(self, viewpoint):
+        self.T = viewpoint.T.detach().clone()
+        self.exposure_a = viewpoint.exposure_a.detach().clone()
+        self.exposure_b = viewpoint.exposure_b.detach().clone()
+
+    def assign(self, viewpoint):
+        with torch.no_grad():
+            viewpoint.T.copy_(self.T)
+            viewpoint.exposure_a.copy_(self.exposure_a)
+            viewpoint.exposure_b.copy_(self.exposure_b)
+            viewpoint.cam_rot_delta.zero_()
+            viewpoint.cam_trans_delta.zero_()
+
+
+def track_frame(viewpoint, gaussians, background, first_order_iters=40, second_order_iters=10,
+                use_first_order_best=True, use_best_loss=True, pipe=Pipe, config=DEFAULT_CONFIG,
+                stack_dim=16, sketch_dim=64, initial_lambda=1e-3, min_lambda=1e-6, max_lambda=1e7,
+                increase_factor=5.0, decrease_factor=5.0, second_order_converged_threshold=1e-5,
+                generator=None, fused=False, fsa_fn=None):
+    """The reference's tracking loop for one frame, reference-shaped Python on the HIP rasteriser
+    (slam_frontend.py:455-822 with override_mode "none"): first-order iterations (Adam on the pose
+    deltas and the exposure; a converged one leaves the whole loop, :623-626), then sketched LM
+    iterations with the lambda rule of :536-545.  Every iteration's L1 residual (before Huber, :510)
+    is compared with the best so far and the rendered state snapshotted (:523-528); the second-order
+    phase starts from the best first-order state (`use_first_order_best`, :465-470); the frame ends
+    at the best state and returns ITS render_pkg (`use_best_loss`, :819-822).
+    Returns (render_pkg, best_l1, best_iteration, iterations).  `fsa_fn(i)` may supply the sketch
+    arguments of second-order iteration i (tests: the native tracker's partitions)."""
+    if fused:
+        from .tracking_fused import FusedPoseOptimizer
+        lr = config["Training"]["lr"]
+        opt = FusedPoseOptimizer(viewpoint, lr["cam_rot_delta"], lr["cam_trans_delta"], lr["exposure_a"],
+                                 lr["exposure_b"])
+        step = tracking_step_first_order_fused
+    else:
+        opt = make_pose_optimizer(viewpoint, config)
+        step = tracking_step_first_order
+    best_l1, best_state, best_pkg, best_it = float("inf"), None, None, -1
+    lam, old_l1 = [initial_lambda], [None]
+
+    def lambda_rule(l1):                       # slam_frontend.py:536-545, evaluated before the solve
+        l1 = float(l1)
+        if old_l1[0] is not None:
+            lam[0] = (max(lam[0] / decrease_factor, min_lambda) if l1 < old_l1[0]
+                      else min(lam[0] * increase_factor, max_lambda))
+        old_l1[0] = l1
+        return lam[0]
+
+    pkg, it = None, 0
+    for itr in range(first_order_iters + second_order_iters):
+        second = itr >= first_order_iters
+        if itr == first_order_iters and best_state is not None and use_first_order_best:
+            best_state.assign(viewpoint)
+        state = TempCamera(viewpoint)            # the state this iteration renders
+        if not second:
+            _, converged, pkg = step(viewpoint, gaussians, opt, background, pipe, config)
+            converged = bool(converged)
+            l1 = float(pkg["tracking_l1"])
+        else:
+            fsa = None if fsa_fn is None else fsa_fn(itr - first_order_iters)
+            l1_t, x, _, _, pkg = tracking_step_second_order(
+                viewpoint, gaussians, background, lambda_rule, 1, stack_dim, sketch_dim, pipe, config,
+                generator, fused_solve=True, fsa=fsa, return_pkg=True)
+            l1 = float(l1_t)
+            converged = bool(x.norm() < second_order_converged_threshold)
+            if converged:                        # the converged step is never assigned (:699-706)
+                state.assign(viewpoint)
+        it += 1
+        if l1 < best_l1:
+            best_l1, best_state, best_pkg, best_it = l1, state, pkg, itr
+        if converged:
+            break
+    if use_best_loss and best_state is not None:
+        best_state.assign(viewpoint)
+        pkg = best_pkg
+    return pkg, best_l1, best_it, it
 
 
 def mapping_step(window: List[ViewCamera], gaussians, gaussian_optimizer, keyframe_optimizer,

@@ -136,7 +136,8 @@ def keyframe_depth(frame_image, depth, opacity, sensor_depth=None, generator=Non
 
 def run_sequence(frames, cam, dev, *, sensor_depth: bool = False, kf_interval: int = 5, window_size: int = 8,
                  init_iters: int = 1050, mapping_iters: int = 150, first_order_iters: int = 40,
-                 second_order_iters: int = 10, seed: int = 0, config: Optional[dict] = None, log=None):
+                 second_order_iters: int = 10, seed: int = 0, config: Optional[dict] = None, log=None,
+                 use_first_order_best: bool = True, use_best_loss: bool = True):
     """Tracking + mapping over `frames`; returns a dict with the estimated poses, timings and the
     final map.  `sensor_depth`: insert keyframes from the frames' depth (RGB-D initialisation) instead
     of the monocular prior / rendered depth."""
@@ -184,12 +185,13 @@ def run_sequence(frames, cam, dev, *, sensor_depth: bool = False, kf_interval: i
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         trk = NativeTracker(vp, gm, bg)
-        it = trk.run(max_iters=first_order_iters, check_every=10)
         if second_order_iters > 0:
             trk.enable_second_order(stack_dim=16, sketch_dim=64, initial_lambda=1e-3, seed=seed + k)
-            for j in range(second_order_iters):
-                trk.step_second_order()
-                it += 1
+        # one frame of the reference's loop incl. its best-iterate bookkeeping (slam_frontend.py:455-822;
+        # use_first_order_best / use_best_loss as in configs/mono/tum/base_config.yaml:268-273); the
+        # tracker's depth / opacity / n_touched buffers end up rendered at the best iterate
+        it = trk.run(max_iters=first_order_iters, check_every=10, second_order_iters=second_order_iters,
+                     use_first_order_best=use_first_order_best, use_best_loss=use_best_loss)
         torch.cuda.synchronize()
         t_track += time.perf_counter() - t0
         n_track_iters += it

@@ -118,6 +118,12 @@ class NativeTracker:
         A.T, A.converged = vp.T.data_ptr(), self.converged.data_ptr()
         (A.lr_rot, A.lr_trans, A.lr_a, A.lr_b, A.beta1, A.beta2, A.eps, A.converged_threshold) = (
             lr_rot, lr_trans, lr_a, lr_b, betas[0], betas[1], eps, converged_threshold)
+        # best-iterate block shared by the first- and second-order iterations (slam_frontend.py:423-425,
+        # 523-528): {best L1, T[16], a, b, index of the best iteration, iteration counter}
+        self.best = torch.zeros(_cabi.TRACK_BEST_FLOATS, device=dev)
+        self.best[0] = float("inf")
+        a.best = self.best.data_ptr()
+        A.sticky_converged = 1
         self.args = a
         self.t = 0
         self._matrices_fresh = False
@@ -170,6 +176,7 @@ class NativeTracker:
         so.base.fwd.bins, so.base.bwd = self.args.fwd.bins, self.args.bwd
         so.base.fwd.shape.pair_capacity = self.args.fwd.shape.pair_capacity
         so.base.adam.T = self.args.adam.T
+        so.base.best = self.args.best
         self.so_t += 1
         so.key = (self.so_seed * 0x9E3779B97F4A7C15 + self.so_t) & 0xFFFFFFFFFFFFFFFF
         _cabi.check(_cabi.lib().mgs_tracking_iteration_second_order(C.byref(so), self._stream()),
@@ -232,11 +239,56 @@ class NativeTracker:
         self._alloc_bins(self.args, int(worst * self.capacity_margin))
         return False
 
+    # ---- best iterate (slam_frontend.py:423-425, 465-470, 523-528, 819-822) -----------------
+    def reset_best(self):
+        self.best.zero_()
+        self.best[0] = float("inf")
+
+    @property
+    def best_loss(self):
+        """||residual||_1 of the best iterate so far (device scalar; inf before the first iteration)."""
+        return self.best[0]
+
+    def best_iteration(self) -> int:
+        """0-based index (first- and second-order iterations counted together) of the best iterate
+        (host sync); -1 before the first iteration."""
+        b = self.best.cpu()
+        return int(b[19].item()) if math.isfinite(b[0].item()) else -1
+
+    def assign_best(self):
+        """TempCamera.assign of the best iterate (slam_frontend.py:37-42): pose and exposure go back to
+        the state whose render had the smallest L1 residual; stays on the device (no sync).  A no-op
+        before the first iteration (best_viewpoint_params is None)."""
+        vp = self.vp
+        self._sync_pose_pointer()
+        with torch.no_grad():
+            have = torch.isfinite(self.best[0])
+            vp.T.copy_(torch.where(have, self.best[1:17].view(4, 4), vp.T))
+            vp.exposure_a.copy_(torch.where(have, self.best[17:18], vp.exposure_a))
+            vp.exposure_b.copy_(torch.where(have, self.best[18:19], vp.exposure_b))
+            vp.cam_rot_delta.zero_()
+            vp.cam_trans_delta.zero_()
+        self._matrices_fresh = False
+
+    def render_current(self):
+        """Forward only at the current pose (the tracker's output buffers: color / depth / opacity /
+        radii / n_touched): after assign_best() these are the best iterate's render_pkg, which the
+        reference hands to the keyframe test (slam_frontend.py:819-822, 1918-1924)."""
+        self._sync_pose_pointer()
+        lib, stream, f = _cabi.lib(), self._stream(), self.args.fwd
+        _cabi.check(lib.mgs_camera_from_pose(self.vp.T.data_ptr(), self.proj.data_ptr(), self.view.data_ptr(),
+                                             self.full.data_ptr(), stream), "mgs_camera_from_pose")
+        _cabi.check(lib.mgs_raster_forward_project(C.byref(f), stream), "mgs_raster_forward_project")
+        _cabi.check(lib.mgs_raster_forward_blend(C.byref(f), stream), "mgs_raster_forward_blend")
+        self._matrices_fresh = True
+        return {"render": self.color, "depth": self.depth, "opacity": self.opacity, "radii": self.radii,
+                "n_touched": self.n_touched, "visibility_filter": self.radii > 0}
+
     def _snapshot(self):
         vp = self.vp
         keep = dict(T=vp.T.detach().clone(), a=vp.exposure_a.detach().clone(), b=vp.exposure_b.detach().clone(),
                     rot=vp.cam_rot_delta.detach().clone(), trans=vp.cam_trans_delta.detach().clone(),
-                    m=self.exp_avg.clone(), v=self.exp_avg_sq.clone(), t=self.t)
+                    m=self.exp_avg.clone(), v=self.exp_avg_sq.clone(), t=self.t, best=self.best.clone())
         if hasattr(self, "lm_state"):
             keep["lm"], keep["so_t"] = self.lm_state.clone(), self.so_t
         return keep
@@ -248,6 +300,7 @@ class NativeTracker:
             vp.exposure_a.copy_(keep["a"]); vp.exposure_b.copy_(keep["b"])
             vp.cam_rot_delta.copy_(keep["rot"]); vp.cam_trans_delta.copy_(keep["trans"])
             self.exp_avg.copy_(keep["m"]); self.exp_avg_sq.copy_(keep["v"])
+            self.best.copy_(keep["best"])
             if "lm" in keep:
                 self.lm_state.copy_(keep["lm"])
                 self.so_t = keep["so_t"]
@@ -255,25 +308,50 @@ class NativeTracker:
         self.converged.zero_()
         self._matrices_fresh = False
 
-    def run(self, max_iters=100, check_every=10, second_order_iters=0):
-        """The reference's loop (slam_frontend.py:493-630): first-order iterations until converged
-        or max_iters (the flag is read back every `check_every` iterations), then
-        `second_order_iters` sketched LM iterations (enable_second_order first).  If ANY iteration
-        overflowed the fixed pair capacity, pose, exposure and optimiser state are restored from the
-        snapshot taken on entry, the workspaces grow and the run is repeated: no truncated render ever
-        reaches the result."""
+    def run(self, max_iters=100, check_every=10, second_order_iters=0, use_first_order_best=True,
+            use_best_loss=True, render_best=True):
+        """The reference's loop for one frame (slam_frontend.py:455-822): first-order iterations until
+        converged or max_iters, then `second_order_iters` sketched LM iterations (enable_second_order
+        first) unless the first order converged (its `break` leaves the whole loop, :623-626).  Every
+        iteration compares the L1 norm of its un-Hubered residual with the best so far on the device
+        (:510, :523-528); with `use_first_order_best` the second-order phase starts from the best
+        first-order state (:465-470), with `use_best_loss` the frame ends at the best state (:819-822)
+        and - `render_best` - the output buffers are re-rendered there, so that n_touched / depth /
+        opacity are the best iterate's (what :1918-1924 consume).  Both default to True as in
+        configs/mono/tum/base_config.yaml:268-273.  The convergence flags are read back every
+        `check_every` iterations only; they are sticky on the device (an iteration enqueued after
+        convergence changes nothing), so the result does not depend on `check_every`.
+        If ANY iteration overflowed the fixed pair capacity, pose, exposure, optimiser and best-iterate
+        state are restored from the snapshot taken on entry, the workspaces grow and the run is
+        repeated: no truncated render ever reaches the result.  Returns the iterations enqueued."""
+        self.reset_best()
+        self.converged.zero_()
         keep = self._snapshot()
         for attempt in range(4):
             it = 0
+            first_converged = False
             while it < max_iters:
                 for _ in range(min(check_every, max_iters - it)):
                     self.step()
                     it += 1
                 if int(self.converged.item()):
+                    first_converged = True
                     break
-            for _ in range(second_order_iters):
-                self.step_second_order()
-                it += 1
+            if second_order_iters > 0 and not first_converged:
+                if use_first_order_best:
+                    self.assign_best()
+                done = 0
+                while done < second_order_iters:
+                    for _ in range(min(check_every, second_order_iters - done)):
+                        self.step_second_order()
+                        done += 1
+                        it += 1
+                    if float(self.lm_state[3].item()) != 0.0:
+                        break
+            if use_best_loss:
+                self.assign_best()
+                if render_best:
+                    self.render_current()
             if self.check_capacity():
                 return it
             self._restore(keep)

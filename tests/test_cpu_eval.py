@@ -142,3 +142,60 @@ def test_eval_ate_and_rendering_drivers(tmp_path):
         return {"render": gt[frame.uid] * 0.9}
     out = E.eval_rendering(frames, None, dataset, render_fn, None, None, kf_indices=[0], interval=5)
     assert out["mean_lpips"] is None and 15 < out["mean_psnr"] < 40 and 0.8 < out["mean_ssim"] < 1.0
+
+
+def test_tracking_best_iterate_bookkeeping_on_a_toy_renderer(monkeypatch):
+    """slam_loops.track_frame (the reference-shaped loop of slam_frontend.py:455-822) on the CPU with
+    a differentiable toy `render`: the criterion is torch.norm(residual, p=1) of
+    losses.get_loss_tracking_per_pixel (:510), the returned state is the best iterate's and the
+    returned render_pkg is the one rendered there (:523-528, :819-822)."""
+    import math
+    from monogs_amd import slam_loops as SL
+    from monogs_amd.losses import get_loss_tracking_per_pixel
+    H, W = 12, 16
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+
+    def toy_render(vp, gaussians, pipe, bg, forward_sketch_args=None):
+        t = vp.T[:3, 3] + vp.cam_trans_delta + 0.3 * vp.cam_rot_delta
+        img = torch.stack([torch.sigmoid(0.3 * (xs - 8) + 4 * t[0]), torch.sigmoid(0.3 * (ys - 6) + 4 * t[1]),
+                           torch.sigmoid(0.2 * (xs + ys - 14) + 4 * t[2])])
+        return {"render": img, "depth": torch.ones(1, H, W), "opacity": torch.ones(1, H, W),
+                "n_touched": torch.zeros(1), "viewspace_points": None, "visibility_filter": None, "radii": None}
+
+    monkeypatch.setattr(SL, "render", toy_render)
+    P = torch.eye(4)
+    fov = 2 * math.atan(1.0)
+
+    def cam(T):
+        v = SL.ViewCamera(1, torch.zeros(3, H, W), T, P, fov, fov, H, W, "cpu")
+        v.original_image = toy_render(SL.ViewCamera(0, torch.zeros(3, H, W), torch.eye(4), P, fov, fov, H, W, "cpu"),
+                                      None, None, None)["render"].detach()
+        v.rgb_pixel_mask_mapping = torch.ones(1, H, W, dtype=torch.bool)
+        return v
+
+    T0 = torch.eye(4)
+    T0[:3, 3] = torch.tensor([0.05, -0.04, 0.03])
+    cfg = {"Training": dict(SL.DEFAULT_CONFIG["Training"])}
+    cfg["Training"]["lr"] = {"cam_rot_delta": 0.05, "cam_trans_delta": 0.05, "exposure_a": 0.02, "exposure_b": 0.02}
+    # by hand
+    v = cam(T0)
+    opt = SL.make_pose_optimizer(v, cfg)
+    l1s, Ts = [], []
+    for _ in range(20):
+        Ts.append(v.T.clone())
+        pk0 = toy_render(v, None, None, None)
+        want = torch.norm(get_loss_tracking_per_pixel(cfg, pk0["render"], pk0["depth"], pk0["opacity"], v).flatten(), p=1)
+        _, _, pkg = SL.tracking_step_first_order(v, None, opt, None, SL.Pipe, cfg)
+        assert abs(float(pkg["tracking_l1"]) - float(want.detach())) <= 1e-5 * float(want.detach())
+        l1s.append(float(want.detach()))
+    k = min(range(20), key=lambda i: l1s[i])
+    assert 0 < k < 19 and l1s[-1] > l1s[k]                   # overshoot: the last iterate is not the best
+    v2 = cam(T0)
+    pkg, best, it, n = SL.track_frame(v2, None, None, first_order_iters=20, second_order_iters=0, config=cfg)
+    assert it == k and n == 20 and abs(best - l1s[k]) <= 1e-6 * l1s[k]
+    assert torch.allclose(v2.T, Ts[k]) and float(v2.cam_trans_delta.abs().sum()) == 0.0
+    v2.cam_trans_delta.data.zero_()
+    assert torch.allclose(pkg["render"], toy_render(v2, None, None, None)["render"], atol=1e-6)
+    v3 = cam(T0)
+    SL.track_frame(v3, None, None, first_order_iters=20, second_order_iters=0, use_best_loss=False, config=cfg)
+    assert torch.allclose(v3.T, v.T)

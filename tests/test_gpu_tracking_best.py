@@ -1,0 +1,155 @@
+"""Best-iterate bookkeeping of the tracking loop (row a12; reference utils/slam_frontend.py:423-425
+snapshot state, :510 criterion = L1 of the un-Hubered residual, :523-528 snapshot on improvement,
+:465-470 re-seed of the second-order phase from the best first-order state, :819-822 final
+restore; both switches are True in configs/mono/tum/base_config.yaml:268-273): the native tracker
+(device-side bookkeeping inside mgs_tracking_iteration[_second_order]) against the reference-shaped
+Python loop `slam_loops.track_frame` on the same kernels."""
+import ctypes as C
+
+import pytest
+import torch
+
+from test_raster_gpu import _loop_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def _frame(view, gauss, dev, uid, T0):
+    from monogs_amd.gaussian_renderer import render
+    from monogs_amd.slam_loops import Pipe
+    bg = torch.zeros(3, device=dev)
+    with torch.no_grad():
+        target = render(view(1, torch.eye(4)), gauss, Pipe, bg)["render"].clone()
+    v = view(uid, T0)
+    v.original_image = target
+    v.rgb_pixel_mask_mapping = (target.sum(0) > 0.01).view(1, *target.shape[1:])
+    return v, bg
+
+
+# learning rates 30x the configuration's: Adam overshoots after a few iterations and the L1 residual
+# RISES again - the last iterate is then not the best one
+BIG_LR = {"cam_rot_delta": 0.09, "cam_trans_delta": 0.03, "exposure_a": 0.02, "exposure_b": 0.02}
+
+
+def _config(lr):
+    from monogs_amd.slam_loops import DEFAULT_CONFIG
+    cfg = {"Training": dict(DEFAULT_CONFIG["Training"])}
+    cfg["Training"]["lr"] = lr
+    return cfg
+
+
+def test_native_first_order_run_returns_the_best_iterate(built):
+    from monogs_amd.pose import SE3_exp
+    from monogs_amd.slam_loops import Pipe, make_pose_optimizer, tracking_step_first_order, track_frame
+    from monogs_amd.tracking_native import NativeTracker
+    sc, gauss, view, dev = _loop_fixture()
+    T0 = SE3_exp(torch.tensor([0.02, -0.015, 0.01, 0.004, -0.006, 0.003]))
+    iters = 24
+    # (1) the trajectory by hand: L1 of every iterate and the state each iteration rendered
+    vh, bg = _frame(view, gauss, dev, 2, T0)
+    cfg = _config(BIG_LR)
+    opt = make_pose_optimizer(vh, cfg)
+    l1s, states = [], []
+    for _ in range(iters):
+        states.append((vh.T.clone(), vh.exposure_a.detach().clone(), vh.exposure_b.detach().clone()))
+        _, _, pkg = tracking_step_first_order(vh, gauss, opt, bg, Pipe, cfg)
+        l1s.append(float(pkg["tracking_l1"]))
+    k = min(range(iters), key=lambda i: l1s[i])
+    assert 0 < k < iters - 3 and l1s[-1] > 1.02 * l1s[k], (k, l1s)     # the loss really rose after iterate k
+    # (2) the reference-shaped loop with the bookkeeping
+    vp, _ = _frame(view, gauss, dev, 3, T0)
+    pkg_p, best_p, it_p, n_p = track_frame(vp, gauss, bg, first_order_iters=iters, second_order_iters=0, config=cfg)
+    assert it_p == k and n_p == iters and abs(best_p - l1s[k]) <= 1e-5 * l1s[k]
+    assert torch.allclose(vp.T, states[k][0], atol=1e-6)
+    # (3) the native tracker: bookkeeping on the device, final pose = iterate k's, outputs re-rendered there
+    vn, _ = _frame(view, gauss, dev, 4, T0)
+    trk = NativeTracker(vn, gauss, bg, lr_rot=BIG_LR["cam_rot_delta"], lr_trans=BIG_LR["cam_trans_delta"])
+    n = trk.run(max_iters=iters, check_every=7)
+    assert n == iters and trk.best_iteration() == k
+    assert abs(trk.best_loss.item() - l1s[k]) <= 2e-3 * l1s[k]
+    assert torch.allclose(vn.T, states[k][0], atol=2e-4)
+    assert torch.allclose(vn.exposure_a, states[k][1], atol=2e-4) and torch.allclose(vn.exposure_b, states[k][2], atol=2e-4)
+    assert float(vn.cam_rot_delta.abs().sum() + vn.cam_trans_delta.abs().sum()) == 0.0
+    # ... and NOT the last iterate
+    assert (vn.T - vh.T).abs().max().item() > 1e-3
+    # render_pkg of the best iterate (n_touched feeds the keyframe test, slam_frontend.py:1918-1924)
+    assert (trk.color - pkg_p["render"]).abs().mean().item() <= 1e-4
+    nt = pkg_p["n_touched"]
+    assert (trk.n_touched - nt).abs().sum().item() <= 0.002 * nt.sum().item() + 5
+    # use_best_loss = False keeps the last iterate
+    vl, _ = _frame(view, gauss, dev, 5, T0)
+    trk2 = NativeTracker(vl, gauss, bg, lr_rot=BIG_LR["cam_rot_delta"], lr_trans=BIG_LR["cam_trans_delta"])
+    trk2.run(max_iters=iters, check_every=24, use_best_loss=False)
+    assert torch.allclose(vl.T, vh.T, atol=2e-4)
+    assert trk2.best_iteration() == k                      # the bookkeeping itself does not depend on the switch
+
+
+def test_native_two_phase_run_matches_the_python_loop(built):
+    """First order (overshooting) then sketched LM iterations: the second-order phase starts from the
+    best first-order state (use_first_order_best) and the frame ends at the overall best state; the
+    native run and the Python loop use the same bucket partitions."""
+    from monogs_amd import _cabi
+    from monogs_amd.pose import SE3_exp
+    from monogs_amd.slam_loops import sketch_args_from_buckets, track_frame
+    from monogs_amd.tracking_native import NativeTracker
+    sc, gauss, view, dev = _loop_fixture()
+    T0 = SE3_exp(torch.tensor([0.02, -0.015, 0.01, 0.004, -0.006, 0.003]))
+    cfg = _config(BIG_LR)
+    fo, so, stack, sketch, seed = 16, 5, 4, 16, 5
+    vn, bg = _frame(view, gauss, dev, 2, T0)
+    H, W = vn.image_height, vn.image_width
+    trk = NativeTracker(vn, gauss, bg, lr_rot=BIG_LR["cam_rot_delta"], lr_trans=BIG_LR["cam_trans_delta"])
+    trk.enable_second_order(stack_dim=stack, sketch_dim=sketch, seed=seed)
+    n = trk.run(max_iters=fo, check_every=4, second_order_iters=so)
+
+    lib = _cabi.lib()
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def fsa_fn(i):       # the partition the native iteration i used (same keyed permutation)
+        key = (seed * 0x9E3779B97F4A7C15 + (i + 1)) & 0xFFFFFFFFFFFFFFFF
+        bucket = torch.empty(H * W, dtype=torch.int32, device=dev)
+        w = torch.empty(H * W, device=dev)
+        _cabi.check(lib.mgs_sketch_assign(H * W, stack, sketch, C.c_uint64(key), bucket.data_ptr(), w.data_ptr(),
+                                          stream), "assign")
+        return sketch_args_from_buckets(bucket, w, H, W, stack, sketch)
+
+    vp, _ = _frame(view, gauss, dev, 3, T0)
+    pkg, best_p, it_p, n_p = track_frame(vp, gauss, bg, first_order_iters=fo, second_order_iters=so, config=cfg,
+                                         stack_dim=stack, sketch_dim=sketch, fsa_fn=fsa_fn)
+    assert n == n_p == fo + so
+    assert it_p >= fo                                       # LM from the best first-order state improves on it
+    assert trk.best_iteration() == it_p
+    assert abs(trk.best_loss.item() - best_p) <= 5e-3 * best_p
+    assert torch.allclose(vn.T, vp.T, atol=5e-4)
+    assert torch.allclose(vn.exposure_a, vp.exposure_a, atol=5e-4)
+    err0 = (T0 - torch.eye(4)).abs().max().item()
+    assert (vn.T.cpu() - torch.eye(4)).abs().max().item() < 0.3 * err0
+    # without the re-seed the second-order phase starts from the overshot LAST first-order iterate
+    vq, _ = _frame(view, gauss, dev, 4, T0)
+    trq = NativeTracker(vq, gauss, bg, lr_rot=BIG_LR["cam_rot_delta"], lr_trans=BIG_LR["cam_trans_delta"])
+    trq.enable_second_order(stack_dim=stack, sketch_dim=sketch, seed=seed)
+    trq.run(max_iters=fo, check_every=4, second_order_iters=1, use_first_order_best=False, use_best_loss=False)
+    vr, _ = _frame(view, gauss, dev, 5, T0)
+    trr = NativeTracker(vr, gauss, bg, lr_rot=BIG_LR["cam_rot_delta"], lr_trans=BIG_LR["cam_trans_delta"])
+    trr.enable_second_order(stack_dim=stack, sketch_dim=sketch, seed=seed)
+    trr.run(max_iters=fo, check_every=4, second_order_iters=1, use_first_order_best=True, use_best_loss=False)
+    assert (vq.T - vr.T).abs().max().item() > 1e-4
+
+
+def test_sticky_convergence_makes_later_iterations_no_ops(built):
+    """The reference leaves its loop at the first converged iteration (slam_frontend.py:623-626); the
+    native flag is read back only every `check_every` iterations, so iterations enqueued after it
+    change nothing: same pose for check_every = 1 and 50."""
+    from monogs_amd.pose import SE3_exp
+    from monogs_amd.tracking_native import NativeTracker
+    sc, gauss, view, dev = _loop_fixture()
+    T0 = SE3_exp(torch.tensor([0.002, -0.0015, 0.001, 0.0004, -0.0006, 0.0003]))
+    res = []
+    for ce in (1, 50):
+        v, bg = _frame(view, gauss, dev, 2, T0)
+        trk = NativeTracker(v, gauss, bg, converged_threshold=2e-3)       # loose: converges within a few iterations
+        n = trk.run(max_iters=50, check_every=ce, use_best_loss=False)
+        res.append((n, v.T.clone(), trk.best.clone()))
+    assert res[0][0] < 50 and res[1][0] == 50
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2][:20], res[1][2][:20])
+    assert int(res[1][2][20].item()) == res[0][0]            # the counter stopped with the convergence
