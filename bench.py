@@ -9,7 +9,12 @@ loss.backward() exercises).
 
 N > 1: keyframe-parallel mapping - Gaussians replicated, one view per rank,
 one all-reduce(sum) of the flat Gaussian-gradient buffer + one all-reduce(max) of the radii
-per step; value = views/s over all ranks ("weak" scaling: per-GPU work fixed).  Launched
+per step; value = views/s over all ranks ("weak" scaling: per-GPU work fixed) through the same
+autograd binding as N = 1, so that the driver's efficiency compares like with like.  A second leg,
+`mapping_sharded`, times BASELINE config 5 through the PRODUCT path: NativeMapper.map on a
+Replica-sized RGB-D window (1200x680, 8 keyframes + 2 old ones) with its 10 views sharded over the
+ranks (bench_legs.bench_mapping_sharded: mapping_iters_per_s, views_per_s, exchange_ms, per-rank
+compute, which ranks held the most views); at N = 1 the same leg runs unsharded (`mapping_replica`).  Launched
 either by the driver (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N
 ...`: RANK / LOCAL_RANK / WORLD_SIZE come from the environment) or directly
 (`python bench.py --gpus N`): with WORLD_SIZE unset this process starts the N ranks itself
@@ -56,6 +61,9 @@ def parse(argv=None):
     ap.add_argument("--no-tracking", action="store_true")
     ap.add_argument("--tracking-iters", type=int, default=100)
     ap.add_argument("--no-mapping", action="store_true")
+    ap.add_argument("--mapping-gaussians", type=int, default=None,
+                    help="map size of the sharded Replica-sized mapping leg (default: --gaussians)")
+    ap.add_argument("--mapping-iters", type=int, default=100)
     ap.add_argument("--no-slam", action="store_true")
     ap.add_argument("--sustain-seconds", type=float, default=2.0)
     ap.add_argument("--lean", action="store_true",
@@ -344,6 +352,18 @@ def main(argv=None):
     dt = max_over_ranks(timed(args.steps))
     ms_per_step = dt / args.steps * 1e3
     value = world * args.steps / dt          # views (frames) per second, whole job
+    # what a MonoGS user gets without touching the autograd engine setting: the same K steps with
+    # PyTorch's default (worker-thread) engine, first-class beside the calibrated figure
+    value_default_engine = None
+    if not distributed:
+        if engine_mt:
+            value_default_engine = value
+        else:
+            torch.autograd.set_multithreading_enabled(True)
+            for _ in range(5):
+                step()
+            value_default_engine = world * args.steps / timed(args.steps)
+            torch.autograd.set_multithreading_enabled(engine_mt)
     D = int(R.last_stats["pairs"])
 
     # ---- multi-rank extras: exchange cost and per-rank compute, measured separately ----
@@ -472,9 +492,17 @@ def main(argv=None):
     if single and not args.no_tracking:
         tracking = bench_tracking(sc, dev, args.tracking_iters)
         map_update = bench_map_update(sc, dev)
+    mapping_replica = mapping_sharded = None
     if single and not args.no_mapping:
-        from monogs_amd.bench_legs import bench_mapping
+        from monogs_amd.bench_legs import bench_mapping, bench_mapping_sharded
         mapping = bench_mapping(sc, dev)
+        mapping_replica = bench_mapping_sharded(dev, 0, 1, None, args.mapping_gaussians or N, args.mapping_iters)
+    if distributed and not args.no_mapping:
+        # config 5 through the product path; EVERY rank takes part (collectives inside)
+        from monogs_amd.bench_legs import bench_mapping_sharded
+        mapping_sharded = bench_mapping_sharded(dev, rank, world, backend, args.mapping_gaussians or N, args.mapping_iters)
+        if mapping_sharded is not None:
+            mapping_sharded["backend"] = "rccl" if backend == "nccl" else f"{backend} (host-staged rehearsal)"
     if single and not args.no_slam:
         from monogs_amd.bench_legs import bench_slam_surrogate
         slam = bench_slam_surrogate(dev)
@@ -495,8 +523,11 @@ def main(argv=None):
         if multi is not None:
             out["multi_gpu"] = multi
             out["exchange_ms"] = multi["exchange_ms"]
+        if value_default_engine is not None:
+            out["value_default_engine"] = round(value_default_engine, 2)
         out.update(extras)
-        for k, v in (("tracking", tracking), ("map_update", map_update), ("mapping", mapping), ("slam", slam)):
+        for k, v in (("tracking", tracking), ("map_update", map_update), ("mapping", mapping),
+                     ("mapping_replica", mapping_replica), ("mapping_sharded", mapping_sharded), ("slam", slam)):
             if v is not None:
                 out[k] = v
         print(json.dumps(out), flush=True)

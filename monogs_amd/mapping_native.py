@@ -142,6 +142,9 @@ class NativeMapper:
         self.loss_accum = self.lanes[0].loss_accum
         self.last_loss = None
         self.overflow_regrows = 0
+        # optional phase timing (bench.py): a list collects, per iteration, HIP events on the main stream
+        # around [activate + this rank's views] [exchange] [statistics fold + optimiser step]
+        self.timing: Optional[list] = None
 
     # ---- distributed helpers ---------------------------------------------------------------------
     def _world(self):
@@ -460,6 +463,10 @@ class NativeMapper:
             if prune:
                 extras = []
             jobs, rank, world = self._shard([(kf, ci, True) for ci, kf in enumerate(window)] + [(kf, -1, False) for kf in extras])
+            ev = None
+            if self.timing is not None and not prune:
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                ev[0].record()
             self._activate()
             self.loss_accum.zero_()
             if not jobs:
@@ -469,7 +476,11 @@ class NativeMapper:
             if prune:
                 self._prune_pass(window, world)
                 return False
+            if ev:
+                ev[1].record()
             self._exchange(world)
+            if ev:
+                ev[2].record()
             update_gaussian = self.iteration_count % tr["gaussian_update_every"] == tr["gaussian_update_offset"]
             reset = (self.iteration_count % tr["gaussian_reset"]) == 0 and not update_gaussian
             self._finish(reset_mode=2 if reset else 0, reset_value=0.4)
@@ -484,8 +495,26 @@ class NativeMapper:
                 gaussian_split = gaussian_split or reset
             g.update_learning_rate(self.iteration_count)
             self.last_loss = self.loss_accum.clone()
+            if ev:
+                ev[3].record()
+                self.timing.append((ev, len(jobs)))
         self._sync_views(window)
         return gaussian_split
+
+    def timing_summary(self):
+        """Mean milliseconds per iteration of the phases recorded while `self.timing` was a list
+        (host sync): this rank's views (activation + forward / loss / backward / per-view Adam of its
+        shard), the exchange (all-reduce(sum) of the flat buffer + all-reduce(max) of the radii), and
+        the statistics fold + Gaussian optimiser step; plus the views this rank rendered per iteration."""
+        torch.cuda.synchronize(self.dev)
+        t = self.timing or []
+        if not t:
+            return None
+        n = len(t)
+        return {"compute_ms": sum(e[0].elapsed_time(e[1]) for e, _ in t) / n,
+                "exchange_ms": sum(e[1].elapsed_time(e[2]) for e, _ in t) / n,
+                "update_ms": sum(e[2].elapsed_time(e[3]) for e, _ in t) / n,
+                "views_per_iteration": sum(j for _, j in t) / n, "iterations": n}
 
     def _sync_views(self, window):
         """Keyframe-parallel: a view's pose and exposure are stepped on the rank that owns it; at

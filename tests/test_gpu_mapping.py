@@ -21,12 +21,12 @@ def _dev():
     return torch.device("cuda", 0)
 
 
-def _window_fixture(N=4000, W=160, H=120, n_views=3, seed=11, dev=None, rgbd=False):
+def _window_fixture(N=4000, W=160, H=120, n_views=3, seed=11, dev=None, rgbd=False, intrinsics=None):
     from monogs_amd import synthetic as S
     from monogs_amd.gaussian_model import GaussianModel
     from monogs_amd.parallel import view_pose
     from monogs_amd.slam_loops import ViewCamera
-    sc = S.make_scene(N, W, H, seed=seed)
+    sc = S.make_scene(N, W, H, seed=seed, intrinsics=intrinsics)
     cam = sc.cam
     fovx, fovy = 2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy)
     g = torch.Generator().manual_seed(seed + 1)
@@ -71,7 +71,7 @@ def _oracle_window_gradients(sc, gm, views, rgbd=False, alpha=0.95):
     per_view, stats = [], dict(gradnorm=torch.zeros(N), denom=torch.zeros(N), radii=torch.zeros(N, dtype=torch.int32),
                                vis=[])
     for v in views:
-        cam = S.make_camera(v.image_width, v.image_height, v.T.detach().cpu())
+        cam = S.make_camera(v.image_width, v.image_height, v.T.detach().cpu(), intrinsics=(v.fx, v.fy, v.cx, v.cy))
         st = oracle_settings(cam, torch.zeros(3))
         theta = torch.zeros(3, requires_grad=True)
         rho = torch.zeros(3, requires_grad=True)
@@ -108,10 +108,23 @@ def _oracle_window_gradients(sc, gm, views, rgbd=False, alpha=0.95):
 
 @pytest.mark.parametrize("rgbd", [False, True])
 def test_native_window_gradients_match_the_oracle(built, rgbd):
+    _check_window_against_oracle(rgbd)
+
+
+def test_native_window_gradients_match_the_oracle_at_the_replica_shape(built):
+    """BASELINE config 5's view shape - Replica office0 calibration, 1200x680, RGB-D objective
+    (configs/rgbd/replica/base_config.yaml:12,27-28; utils/slam_utils.py:243-253) - through the native
+    mapping iteration against the torch oracle, on a 3-view window at a reduced map size (the oracle
+    walks 3225 tiles per view on the CPU)."""
+    from monogs_amd import synthetic as S
+    _check_window_against_oracle(True, N=12000, W=1200, H=680, intrinsics=S.REPLICA_INTRINSICS, seed=17)
+
+
+def _check_window_against_oracle(rgbd, **fixture_kw):
     from monogs_amd.mapping_native import NativeMapper
     from monogs_amd.pose import SE3_exp
     dev = _dev()
-    sc, gm, views = _window_fixture(dev=dev, rgbd=rgbd)
+    sc, gm, views = _window_fixture(dev=dev, rgbd=rgbd, **fixture_kw)
     want, stats, per_view, total = _oracle_window_gradients(sc, gm, views, rgbd=rgbd)
     T0 = [v.T.clone() for v in views]
     ab0 = [(float(v.exposure_a), float(v.exposure_b)) for v in views]
@@ -354,3 +367,66 @@ def test_initialize_map_runs_the_reference_schedule(built):
     torch.cuda.synchronize()
     assert float(gm.get_opacity.max()) < 0.011
     assert mp.occ_aware_visibility[0].shape[0] == len(gm)
+
+
+def replica_window_fixture(dev, N=60000, n_kf=10, seed=41):
+    """BASELINE config 5's shape on one GPU: Replica office0 calibration, 1200x680, RGB-D, `n_kf`
+    keyframes (a window of 8 + the old keyframes the 2 random extra views are drawn from).  The
+    targets are renders of the scene itself with different colours / a depth offset, so that the
+    objective has something to learn."""
+    from monogs_amd import synthetic as S
+    from monogs_amd.gaussian_renderer import render
+    from monogs_amd.slam_loops import Pipe
+    sc, gm, views = _window_fixture(N=N, W=1200, H=680, n_views=n_kf, seed=seed, dev=dev, rgbd=True,
+                                    intrinsics=S.REPLICA_INTRINSICS)
+    bg = torch.zeros(3, device=dev)
+    with torch.no_grad():
+        for v in views:
+            pkg = render(v, gm, Pipe, bg)
+            v.original_image = pkg["render"].clamp(0, 1).clone()
+            v.rgb_pixel_mask_mapping = (v.original_image.sum(0) > 0.01).view(1, 680, 1200)
+            v.gt_depth = (pkg["depth"] * 1.02).clone()
+            v.exposure_a.fill_(1.0)
+            v.exposure_b.fill_(0.0)
+        gm._features_dc.mul_(0.4)
+    gm.unique_kfIDs = (torch.arange(N, device=dev) % n_kf).to(torch.int32)
+    return sc, gm, views
+
+
+def test_native_mapper_at_the_config5_shape(built):
+    """NativeMapper over an 8-view window + 2 random old keyframes, RGB-D, 1200x680 (Replica office0
+    calibration), 60 000 Gaussians - the per-iteration work of BASELINE config 5 on one GPU
+    (utils/slam_backend.py:183-247): finite, complete renders, the summed objective decreases, every
+    one of the 10 views enters the statistics, the prune pass builds n_obs from 8 visibilities."""
+    from monogs_amd.mapping_native import NativeMapper
+    dev = _dev()
+    N = 60000
+    _, gm, views = replica_window_fixture(dev, N=N)
+    cfg = {"Training": {"monocular": False, "window_size": 8, "gaussian_update_every": 1000}}
+    mp = NativeMapper(gm, torch.zeros(3, device=dev), config=cfg)
+    for i, v in enumerate(views):
+        mp.add_keyframe(i, v)
+    window = [9, 8, 7, 6, 5, 4, 3, 2]
+    mp.set_window(window)
+    T0 = {v.uid: v.T.clone() for v in views}
+    mp.map(iters=1)
+    l0 = float(mp.last_loss)
+    assert float(gm.denom.max()) == 10.0                   # 8 window views + 2 extras in the statistics
+    mp.map(iters=14)
+    torch.cuda.synchronize()
+    l1 = float(mp.last_loss)
+    assert mp.check_capacity()
+    assert math.isfinite(l0) and math.isfinite(l1) and l1 < 0.8 * l0, (l0, l1)
+    for attr in ("_xyz", "_features_dc", "_opacity", "_scaling", "_rotation"):
+        assert bool(torch.isfinite(getattr(gm, attr)).all()), attr
+    assert float(gm.denom.max()) == 150.0 and float(gm.xyz_gradient_accum.max()) > 0
+    assert set(mp.occ_aware_visibility) == set(window)
+    assert mp.color.shape == (3, 680, 1200) and bool(torch.isfinite(mp.color).all())
+    # window positions 0..2 (pose_window) are pose-optimised, old keyframes (extras) never move
+    for uid in (9, 8, 7):
+        assert not torch.equal(views[uid].T, T0[uid])
+    for uid in (0, 1, 6, 2):
+        assert torch.equal(views[uid].T, T0[uid]), uid
+    mp.map(prune=True)
+    torch.cuda.synchronize()
+    assert gm.n_obs.shape[0] == len(gm) == N and int(gm.n_obs.max()) == 8     # RGB-D: counted, not pruned (:286)

@@ -97,12 +97,21 @@ def test_bench_gpus_2_starts_two_ranks(built):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--gaussians", "20000", "--width", "320", "--height", "240", "--lean", "--profile-steps", "0"],
-                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+                        "--gaussians", "20000", "--width", "320", "--height", "240", "--profile-steps", "0",
+                        "--no-cpu-baseline", "--no-tracking", "--no-slam", "--sustain-seconds", "0",
+                        "--mapping-gaussians", "30000", "--mapping-iters", "6"],
+                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["config"]["views_per_step"] == 2
+    # the config-5 leg: NativeMapper.map, Replica-sized RGB-D window of 8 + 2 views sharded over the 2 ranks
+    ms = out["mapping_sharded"]
+    assert ms["world"] == 2 and ms["views_per_rank"] == [5.0, 5.0] and ms["ranks_with_most_views"] == [0, 1]
+    assert ms["mapping_iters_per_s"] > 0 and abs(ms["views_per_s"] - 10 * ms["mapping_iters_per_s"]) < 0.1
+    assert ms["exchange_ms"] > 0 and len(ms["compute_ms_per_rank"]) == 2 and all(c > 0 for c in ms["compute_ms_per_rank"])
+    exact = (30000 * (3 + 3 + 1 + 3 + 4) + 2 * 30000) * 4 + 30000 * 4         # sections are padded to 64 floats
+    assert exact <= ms["exchange_bytes"] <= exact + 8 * 64 * 4 and "1200x680" in ms["workload"]
     mg = out["multi_gpu"]
     assert len(mg["compute_ms_per_rank"]) == 2 and mg["exchange_ms"] > 0 and out["exchange_ms"] == mg["exchange_ms"]
     assert mg["exchange_bytes"] == (20000 * (3 + 3 + 4 + 1 + 3) + 2 * 20000) * 4 + 20000 * 4
@@ -119,16 +128,21 @@ def test_bench_gpus_2_starts_two_ranks(built):
 # flat buffer that is all-reduced, every rank applies the identical optimiser step, densification
 # (seeded split noise) and prune decision (all-gathered visibility).  Result must equal the
 # single-process NativeMapper on the same window.
-def _native_mapping_run(group_world, dev, iters=4):
+def _native_mapping_run(group_world, dev, iters=4, replica=False):
     from monogs_amd.mapping_native import NativeMapper
-    from test_gpu_mapping import _window_fixture
-    _, gm, views = _window_fixture(N=3000, n_views=6, dev=dev, seed=31)
-    gm.unique_kfIDs = (torch.arange(3000, device=dev) % 6).to(torch.int32)
-    cfg = {"Training": {"window_size": 4, "gaussian_update_every": 3, "gaussian_update_offset": 0}}
+    from test_gpu_mapping import _window_fixture, replica_window_fixture
+    if replica:     # BASELINE config 5's shape: RGB-D, 1200x680, window 8 + 2 old keyframes
+        _, gm, views = replica_window_fixture(dev, N=50000, n_kf=10, seed=43)
+        cfg = {"Training": {"monocular": False, "window_size": 8, "gaussian_update_every": 3, "gaussian_update_offset": 0}}
+        window = [9, 8, 7, 6, 5, 4, 3, 2]
+    else:
+        _, gm, views = _window_fixture(N=3000, n_views=6, dev=dev, seed=31)
+        gm.unique_kfIDs = (torch.arange(3000, device=dev) % 6).to(torch.int32)
+        cfg = {"Training": {"window_size": 4, "gaussian_update_every": 3, "gaussian_update_offset": 0}}
+        window = [5, 4, 3, 2]
     mp_ = NativeMapper(gm, torch.zeros(3, device=dev), config=cfg)
     for i, v in enumerate(views):
         mp_.add_keyframe(i, v)
-    window = [5, 4, 3, 2]
     mp_.set_window(window)
     mp_.map(window, iters=iters)          # iteration 3 densifies; views 0, 1 are the random extras
     n_mid = len(gm)
@@ -144,7 +158,7 @@ def _native_mapping_run(group_world, dev, iters=4):
     return out
 
 
-def _native_mapping_worker(rank, world, port, ret):
+def _native_mapping_worker(rank, world, port, ret, replica=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -152,7 +166,7 @@ def _native_mapping_worker(rank, world, port, ret):
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    out = _native_mapping_run(world, dev)
+    out = _native_mapping_run(world, dev, replica=replica)
     ret[rank] = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in out.items()}
     dist.barrier()
     dist.destroy_process_group()
@@ -187,6 +201,32 @@ def test_native_mapper_sharded_over_two_ranks_matches_single_process(built):
         assert abs(r0[f"a{uid}"] - single[f"a{uid}"]) < 2e-4
         moved = not np.allclose(r0[f"T{uid}"], _pose0(uid))
         assert moved == (uid in (5, 4, 3))          # window positions 0..2: pose optimised + update_pose
+
+
+def test_native_mapper_sharded_at_the_config5_shape(built):
+    """The same check at BASELINE config 5's shape (RGB-D, 1200x680 Replica calibration, 50 000
+    Gaussians, window of 8 + 2 old keyframes = 5 views per rank on 2 ranks): the sharded replicas stay
+    bit-identical, incl. a densification, and equal the single-process NativeMapper."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    single = _native_mapping_run(1, torch.device("cuda", 0), replica=True)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + ((os.getpid() + 419) % 500)
+    mp.spawn(_native_mapping_worker, args=(2, port, ret, True), nprocs=2, join=True)
+    r0, r1 = ret[0], ret[1]
+    assert r0["n_mid"] == r1["n_mid"] and r0["n"] == r1["n"]
+    for k in ("xyz", "opacity", "scaling", "ids", "n_obs"):
+        assert np.array_equal(r0[k], r1[k]), k
+    assert single["n_mid"] == r0["n_mid"] and single["n"] == r0["n"] and single["n_mid"] != 50000
+    assert np.array_equal(single["ids"].numpy(), r0["ids"]) and np.array_equal(single["n_obs"].numpy(), r0["n_obs"])
+    for k, tol in (("xyz", 2e-4), ("opacity", 5e-3), ("scaling", 2e-4)):
+        close = (np.abs(single[k].numpy() - r0[k]) <= tol).mean()
+        assert close > 0.995, (k, close)
+    assert abs(single["loss"] - r0["loss"]) <= 1e-4 * abs(single["loss"])
+    for uid in range(10):
+        assert np.array_equal(r0[f"T{uid}"], r1[f"T{uid}"]) and r0[f"a{uid}"] == r1[f"a{uid}"], uid
+        assert np.allclose(r0[f"T{uid}"], single[f"T{uid}"].numpy(), atol=5e-5), uid
 
 
 def _pose0(uid):
