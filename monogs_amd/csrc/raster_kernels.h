@@ -124,6 +124,15 @@ constexpr int kSeg = 64;            // splats staged at a time by the blend kern
 // round of items, which run two or three to a SIMD at the latency of a lone wave; shorter items make
 // that round shorter, at the price of a second per-pixel state load and checkpoint per segment.
 constexpr int kItem = 32;
+// Items per workgroup of the plain blend backward: kBwdGroup consecutive items of ONE tile run as the
+// waves of one workgroup and share the tile's per-pixel state (upstream gradients, final colour /
+// depth, list lengths) through LDS - loaded once per workgroup instead of once per item.  The
+// forward pads every tile's item count to a multiple of kBwdGroup (empty items: 0 splats), so a
+// workgroup never straddles two tiles.
+constexpr int kBwdGroup = 4;
+__host__ __device__ inline int items_of_tile(int pairs) {
+  return ((pairs + kItem - 1) / kItem + kBwdGroup - 1) / kBwdGroup * kBwdGroup;
+}
 constexpr int kBinBlocks = 512;    // workgroups of the LDS-privatised binning passes
 constexpr int kBinSmallMap = 65536;  // up to here the binning passes run 256-thread workgroups of 256 Gaussians
 constexpr int kBinMaxTilesLds = 12288;   // T above this falls back to global atomics
@@ -160,7 +169,7 @@ inline Layout make_layout(const mgs_raster_shape& s) {
   o = 0;
   L.keys = o; o = align_up(o + cap * 8);
   L.payload = o; o = align_up(o + cap * 4);
-  L.max_segs = cap / kItem + T;
+  L.max_segs = cap / kItem + (uint64_t)kBwdGroup * T;     // ceil(n_t / kItem) padded to a multiple of kBwdGroup per tile
   L.seg_rec = o; o = align_up(o + L.max_segs * 16);
   L.ckpt = o; o = align_up(o + L.max_segs * 5 * 256 * 4);
   L.bins_bytes = o;
