@@ -3,7 +3,7 @@
 //                    front-to-back replay from the forward's per-item checkpoint; per splat the
 //                    ten screen-space sums are reduced over the wave in registers (permlane swap +
 //                    DPP reduce-scatter) and stored ONCE, with plain stores, at the pair's slot
-//   k_preprocess_bwd 1 thread / Gaussian: streams its contiguous slots, chains to
+//   k_preprocess_bwd 1 thread / Gaussian (the wave stages its contiguous run of pair records in LDS), chains to
 //                    means3D / scale / rot / SH / opacity / means2D and the per-Gaussian pose
 //                    gradient, block-reduced to one partial per workgroup; in mapping mode it also
 //                    chains through the model's activations and accumulates over the views
@@ -202,7 +202,10 @@ __global__ __launch_bounds__(64 * G, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_
   // (S = colour/depth still to come BEHIND the splats visited so far, background included,
   // F = prefix colour from the checkpoint).  dL/dalpha only ever needs S through g.S, and
   // g.S updates with one FMA per splat (gS -= w * g.c).
-  int last[4];
+  // per quadrant: how many of this item's positions lie in front of the pixel's last contribution
+  // (n_contrib - base, clamped to [0, 255]), one byte each: ONE register instead of four
+  static_assert(kItem <= 255, "packed per-quadrant list ends");
+  unsigned int lastp = 0u;
   float g0[4], g1[4], g2[4], gd[4], T[4], gS[4];
   const float bg0 = P.bg[0], bg1 = P.bg[1], bg2 = P.bg[2];
   const float* ck = (base > 0 && nb > 0) ? P.ckpt + (size_t)item * (5 * 256) : nullptr;
@@ -223,7 +226,6 @@ __global__ __launch_bounds__(64 * G, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     g0[q] = g1[q] = g2[q] = gd[q] = 0.f;
-    last[q] = 0;
     T[q] = 0.f;
     gS[q] = 0.f;
   }
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(64 * G, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_
         const float c0 = pc.x - k4[q].y, c1 = pc.y - k4[q].z, c2 = pc.z - k4[q].w, cd = pc.w - k3[q];
         const float gs = g0[q] * c0 + g1[q] * c1 + g2[q] * c2 + gd[q] * cd;
         const bool on = qlast[q] > base && ln_q > base;       // as in the ungrouped form below
-        last[q] = qlast[q] > base ? ln_q : 0;
+        lastp |= (unsigned int)min(max((qlast[q] > base ? ln_q : 0) - base, 0), 255) << (8 * q);
         T[q] = on ? k4[q].x : 0.f;
         gS[q] = on ? gs : 0.f;
         if (qlast[q] <= base) { g0[q] = 0.f; g1[q] = 0.f; g2[q] = 0.f; gd[q] = 0.f; }
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(64 * G, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_
       // stops checkpointing a quadrant once all its pixels are saturated: never let that
       // unwritten state into the arithmetic); the same for a quadrant that is done as a whole
       const bool on = qlast[q] > base && ln_q > base;
-      last[q] = qlast[q] > base ? ln_q : 0;
+      lastp |= (unsigned int)min(max((qlast[q] > base ? ln_q : 0) - base, 0), 255) << (8 * q);
       T[q] = on ? k4[q].x : 0.f;
       gS[q] = on ? gs : 0.f;
       if (qlast[q] <= base) { g0[q] = 0.f; g1[q] = 0.f; g2[q] = 0.f; gd[q] = 0.f; }
@@ -345,17 +347,21 @@ __global__ __launch_bounds__(64 * G, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_
   const bool wextra = lane == 31 || lane == 63;
   // dword of the pair record this lane stores after the reduction (-1: none).  Record layout:
   // S1 | Sx Sy | Sxx Sxy | Syy | Rr Rg Rb | Rd.  POSE reduces (Sx, Sy, Sxx, Sxy | Syy, Rd) only.
-  const int wofs = POSE ? (wextra ? (lane == 31 ? 5 : 9)
+  const int wofs_ = POSE ? (wextra ? (lane == 31 ? 5 : 9)
                                   : ((lane & 15) == 0 ? 1 + ((lane >> 5) & 1) + 2 * ((lane >> 4) & 1) : -1))
                         : (wextra ? (lane == 31 ? 8 : 9)
                                   : ((lane & 7) == 0 ? ((lane >> 5) & 1) + 2 * ((lane >> 4) & 1) + 4 * ((lane >> 3) & 1) : -1));
+  // byte offset of that dword as an unsigned register (0x80000000...: none): ONE VGPR for offset and
+  // predicate - a 64-bit per-lane address and a sign-extended index cost four and spilled at 7 waves / SIMD
+  const unsigned int wofs4 = wofs_ >= 0 ? (unsigned int)wofs_ * 4u : 0x80000000u;
   // Packed operands: the per-quadrant body is written on float2 values so that it maps onto
   // v_pk_{add,mul,fma}_f32 without register shuffles (measured on gfx950: a packed FMA issues
   // in about the time of a scalar one, so pairs of independent FMAs halve their issue cost).
   v2f Pq[4], G01[4], G2d[4];
+  const v2f P0 = {(float)qx, (float)qy};       // this lane's pixel in quadrant 0; quadrant q adds (8 (q & 1), 8 (q >> 1))
 #pragma unroll
   for (int q = 0; q < 4; q++) {
-    Pq[q] = v2f{(float)(qx + 8 * (q & 1)), (float)(qy + 8 * (q >> 1))};
+    Pq[q] = v2f{(float)(8 * (q & 1)), (float)(8 * (q >> 1))};       // compile-time constants: no registers
     G01[q] = v2f{g0[q], g1[q]};
     G2d[q] = v2f{g2[q], gd[q]};
   }
@@ -365,8 +371,9 @@ __global__ __launch_bounds__(64 * G, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_
   unsigned long long mq[4] = {0ull, 0ull, 0ull, 0ull};
   unsigned long long written = 0ull;
   // one splat: (u, v, bd2) = its staged record; mq = the quadrants the segment's splats reach
-  auto visit = [&](int j, const float4 u, const float4 v, const float2 bd2) {
-    const v2f mu = {u.x, u.y}, RG = {v.z, v.w}, BD = {bd2.x, bd2.y};
+  auto visit = [&](int j, const float4 u, const float4 v) {
+    const float2 bd2 = s_r2[j];        // (b, depth): needed late in the visit, not worth two prefetch registers
+    const v2f mu = v2f{u.x, u.y} - P0, RG = {v.z, v.w}, BD = {bd2.x, bd2.y};
     const int idx = sub_base + j;
     const v2f* cf2 = reinterpret_cast<const v2f*>(&s_coef[SKETCH ? j : 0][0]);   // [feature][tau pair]
     // pixel sums of this splat: S1 | (Sx, Sy) | (Sxx, Sxy) | Syy | (Rr, Rg) | (Rb, Rd)
@@ -382,7 +389,7 @@ __global__ __launch_bounds__(64 * G, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_
       const float pw = fminf(0.f, d.x * (u.z * d.x + u.w * d.y) + v.x * d.y * d.y);
       const float ar = v.y * __builtin_amdgcn_exp2f(pw);
       const float al = fminf(kAlphaMax, ar);
-      const bool k = idx < last[q] && al >= kAlphaMin;
+      const bool k = (unsigned int)(idx - base) < ((lastp >> (8 * q)) & 0xffu) && al >= kAlphaMin;
       MGS_BLANES(k);
       if (__ballot(k) == 0ull) continue;              // wave-uniform
       any = true;
@@ -438,8 +445,10 @@ __global__ __launch_bounds__(64 * G, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_
         wave_sum10_scatter(r, b3mask, mres, eres);
       }
       const int sj = __builtin_amdgcn_readlane(slot, j);
-      float* dst = reinterpret_cast<float*>(B.pair_grad) + (size_t)max(sj, 0) * 12;
-      if (wofs >= 0 && sj >= 0) dst[wofs] = wextra ? eres : mres;
+      if (sj >= 0) {       // wave-uniform; the record's base is a scalar, the lane adds its 32-bit byte offset
+        char* rowb = reinterpret_cast<char*>(B.pair_grad) + (size_t)sj * (kPairStride * 4);
+        if ((int)wofs4 >= 0) *reinterpret_cast<float*>(rowb + wofs4) = wextra ? eres : mres;
+      }
       written |= 1ull << j;
     }
   };
@@ -506,20 +515,18 @@ __global__ __launch_bounds__(64 * G, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_
       if (todo != 0ull) {
         int j0 = __builtin_ctzll(todo);
         float4 u0 = s_r0[j0], v0 = s_r1[j0];
-        float2 w0 = s_r2[j0];
         while (true) {
           todo &= todo - 1ull;
           const int j1 = __builtin_ctzll(todo) & 63;       // todo == 0: harmless read of slot 63
           const float4 u1 = s_r0[j1], v1 = s_r1[j1];
-          const float2 w1 = s_r2[j1];
           __builtin_amdgcn_sched_barrier(0);               // keep the prefetch above the arithmetic
-          visit(j0, u0, v0, w0);
+          visit(j0, u0, v0);
           if (todo == 0ull) break;
           todo &= todo - 1ull;
           j0 = __builtin_ctzll(todo) & 63;
-          u0 = s_r0[j0]; v0 = s_r1[j0]; w0 = s_r2[j0];
+          u0 = s_r0[j0]; v0 = s_r1[j0];
           __builtin_amdgcn_sched_barrier(0);
-          visit(j1, u1, v1, w1);
+          visit(j1, u1, v1);
           if (todo == 0ull) break;
         }
       }
@@ -528,9 +535,10 @@ __global__ __launch_bounds__(64 * G, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_
     // splats of the segment that no pixel reached: zero record
     if (!JONLY && slot >= 0 && !((written >> lane) & 1ull))
     {
-      float4* dst = B.pair_grad + (size_t)slot * 3;
-      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      dst[0] = z; dst[1] = z; dst[2] = z;
+      float2* dst = reinterpret_cast<float2*>(B.pair_grad + (size_t)slot * kPairStride);     // 40-B records: 8-B aligned
+      const float2 z = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < kPairStride / 2; i++) dst[i] = z;
     }
   }
   }   // rep
@@ -641,34 +649,69 @@ __global__ __launch_bounds__(256) void k_sketch_bucket(KP P, KB B) {
 template <bool MAP, bool SH0 = false>
 __global__ __launch_bounds__(kPreBlock) void k_preprocess_bwd(KP P, KB B) {
   __shared__ float s_tau[kPreBlock / 64][6];
+  __shared__ float2 s_stage[kPreBlock / 64][kPreChunk * (kPairStride / 2)];     // 5 KB per wave
   const int idx = blockIdx.x * kPreBlock + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (idx < P.N) {
-    // Every load that depends on idx alone is issued here, ahead of any use and outside the
-    // "visible" branch: one memory round trip, then one more for the pair records (it was five in a
-    // row: record -> slot offsets -> pair records -> scales / rotation -> model parameters).
-    const float4* recp = reinterpret_cast<const float4*>(P.rec + idx);
-    const float4 r0 = recp[0], r1 = recp[1], r2 = recp[2];
-    const float p[3] = {P.means[3 * idx], P.means[3 * idx + 1], P.means[3 * idx + 2]};
-    const int pair_cnt = P.pair_count[idx], pair_o = P.pair_off[idx];
-    // per_block is a multiple of kPreBlock: the binning block of this whole workgroup (scalar load)
-    const int pair_b = P.block_prefix[(blockIdx.x * kPreBlock) / P.per_block];
-    float sc[3] = {1.f, 1.f, 1.f}, c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float4 qq = make_float4(1.f, 0.f, 0.f, 0.f);
-    if (P.covp) {
+  // Every load that depends on idx alone is issued here, ahead of any use and outside the
+  // "visible" branch: one memory round trip, then one more for the pair records (it was five in a
+  // row: record -> slot offsets -> pair records -> scales / rotation -> model parameters).
+  const bool valid = idx < P.N;
+  const int idc = valid ? idx : 0;            // clamped: lanes behind the last Gaussian load entry 0 and drop it
+  const float4* recp = reinterpret_cast<const float4*>(P.rec + idc);
+  const float4 r0 = recp[0], r1 = recp[1], r2 = recp[2];
+  const float p[3] = {P.means[3 * idc], P.means[3 * idc + 1], P.means[3 * idc + 2]};
+  const int pair_cnt = valid ? P.pair_count[idc] : 0, pair_o = P.pair_off[idc];
+  // per_block is a multiple of kPreBlock: the binning block of this whole workgroup (scalar load)
+  const int pair_b = P.block_prefix[(blockIdx.x * kPreBlock) / P.per_block];
+  float sc[3] = {1.f, 1.f, 1.f}, c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float4 qq = make_float4(1.f, 0.f, 0.f, 0.f);
+  if (P.covp) {
 #pragma unroll
-      for (int i = 0; i < 6; i++) c6[i] = P.covp[6 * (size_t)idx + i];
-    } else {
-      sc[0] = P.scales[3 * idx]; sc[1] = P.scales[3 * idx + 1]; sc[2] = P.scales[3 * idx + 2];
-      qq = reinterpret_cast<const float4*>(P.rots)[idx];
+    for (int i = 0; i < 6; i++) c6[i] = P.covp[6 * (size_t)idc + i];
+  } else {
+    sc[0] = P.scales[3 * idc]; sc[1] = P.scales[3 * idc + 1]; sc[2] = P.scales[3 * idc + 2];
+    qq = reinterpret_cast<const float4*>(P.rots)[idc];
+  }
+  float map_o = 0.f;
+  float4 map_qr = make_float4(1.f, 0.f, 0.f, 0.f);
+  if constexpr (MAP) {
+    map_o = P.opac[idc];
+    map_qr = reinterpret_cast<const float4*>(B.map.raw_rot)[idc];
+  }
+  // ---- the pair records of this wave's 64 Gaussians: ONE contiguous run of 40-B records (slots are
+  // Gaussian-major in index order), streamed into LDS with coalesced 8-B loads, kPreChunk records per
+  // trip; every lane then adds up its own Gaussian's records in slot order.  (One thread chasing its
+  // own records read 16 B per lane at a 40..48-B stride: 3.4 TB/s.)
+  float acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  {
+    const bool has = valid && __float_as_int(r1.w) > 0 && pair_cnt > 0;
+    // clamped to the capacity of the pair_grad buffer (see k_blend_bwd)
+    const int s0 = has ? min(pair_b + pair_o, P.cap) : 0x7fffffff;
+    const int s1 = has ? min(min(pair_b + pair_o, P.cap) + pair_cnt, P.cap) : 0;
+    int lo = s0, hi = s1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_xor(lo, off)); hi = max(hi, __shfl_xor(hi, off)); }
+    const int S0 = __builtin_amdgcn_readfirstlane(lo), S1 = __builtin_amdgcn_readfirstlane(hi);
+    float2* stage = s_stage[wave];
+    const float2* src = reinterpret_cast<const float2*>(B.pair_grad);
+    for (int c = S0; c < S1; c += kPreChunk) {                   // wave-uniform
+      const int n = min(kPreChunk, S1 - c) * (kPairStride / 2);  // 8-B words of this trip
+      const size_t w0 = (size_t)c * (kPairStride / 2);
+#pragma unroll 2
+      for (int i = lane; i < n; i += 64) stage[i] = src[w0 + i];
+      wave_lds_fence();
+      const int a0 = max(s0, c), a1 = min(s1, c + kPreChunk);
+      for (int sl = a0; sl < a1; sl++) {
+        const float2* rp = stage + (sl - c) * (kPairStride / 2);
+        const float2 v0 = rp[0], v1 = rp[1], v2 = rp[2], v3 = rp[3], v4 = rp[4];
+        acc[0] += v0.x; acc[1] += v0.y; acc[2] += v1.x; acc[3] += v1.y; acc[4] += v2.x;
+        acc[5] += v2.y; acc[6] += v3.x; acc[7] += v3.y; acc[8] += v4.x; acc[9] += v4.y;
+      }
+      wave_lds_fence();                                          // before the next trip overwrites the stage
     }
-    float map_o = 0.f;
-    float4 map_qr = make_float4(1.f, 0.f, 0.f, 0.f);
-    if constexpr (MAP) {
-      map_o = P.opac[idx];
-      map_qr = reinterpret_cast<const float4*>(B.map.raw_rot)[idx];
-    }
+  }
+  if (valid) {
     __builtin_amdgcn_sched_barrier(0);
     const int radius = __float_as_int(r1.w);
     const unsigned int flags = __float_as_uint(r2.w);
@@ -678,28 +721,10 @@ __global__ __launch_bounds__(kPreBlock) void k_preprocess_bwd(KP P, KB B) {
     float grgb[3] = {0.f, 0.f, 0.f};
     if (radius > 0) {
       float a[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      // clamped to the capacity of the pair_grad buffer (see k_blend_bwd)
-      const int s0 = min(pair_b + pair_o, P.cap), s1 = min(s0 + pair_cnt, P.cap);
-      // four slots in flight per trip (predicated loads, issued back to back): the loop is bound by
-      // load latency, not by bytes - one slot per trip costs one round trip per pair of the Gaussian
-      for (int s = s0; s < s1; s += 4) {
-        float4 x[4], y[4], z[4];
+      // the wave staged its whole run of records in LDS above; this Gaussian's share, in slot order
+      // (the summation order is fixed: bit-reproducible, also across ranks)
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-          x[u] = y[u] = z[u] = zero;
-          if (s + u < s1) {
-            const float4* src = B.pair_grad + (size_t)(s + u) * 3;
-            x[u] = src[0]; y[u] = src[1]; z[u] = src[2];
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {     // same summation order as one slot per trip
-          a[0] += x[u].x; a[1] += x[u].y; a[2] += x[u].z; a[3] += x[u].w;
-          a[4] += y[u].x; a[5] += y[u].y; a[6] += y[u].z; a[7] += y[u].w;
-          a[8] += z[u].x; a[9] += z[u].y;
-        }
-      }
+      for (int k = 0; k < 10; k++) a[k] = acc[k];
       if (!MAP && !B.g_means3D) { a[0] = 0.f; a[6] = 0.f; a[7] = 0.f; a[8] = 0.f; }   // pose-only: not produced
       // a[] = raw pixel sums (S1, Sx, Sy, Sxx, Sxy, Syy, Rr, Rg, Rb, Rd) over all tiles of
       // the Gaussian; the conic / opacity are per-Gaussian, so the linear map to screen-space

@@ -201,7 +201,7 @@ static int32_t raster_backward_impl(const mgs_backward_args* args, void* stream,
   KB B;
   B.grad_color = args->grad_color; B.grad_depth = args->grad_depth;
   char* w = (char*)args->bwd;
-  B.pair_grad = (float4*)(w + L.pair_grad);
+  B.pair_grad = (float*)(w + L.pair_grad);
   B.tau_partial = (float*)(w + L.tau_partial);
   B.g_means3D = args->grad_means3D; B.g_means2D = args->grad_means2D;
   B.g_colors = args->grad_colors; B.g_opac = args->grad_opacities;

@@ -65,7 +65,7 @@ struct KM {   // mapping mode of the preprocess backward (mgs_map_accum_args)
 
 struct KB {   // backward extras
   const float *grad_color, *grad_depth;
-  float4* pair_grad;       // cap x 3 float4
+  float* pair_grad;        // cap x kPairStride floats: the ten raw pixel sums of a pair at its slot
   float* tau_partial;      // nblocks x 6
   float *g_means3D, *g_means2D, *g_colors, *g_opac, *g_scales, *g_rots, *g_cov, *g_tau;
   int sketch_mode, sketch_dim, stack_dim;
@@ -133,6 +133,10 @@ constexpr int kBwdGroup = 4;
 __host__ __device__ inline int items_of_tile(int pairs) {
   return ((pairs + kItem - 1) / kItem + kBwdGroup - 1) / kBwdGroup * kBwdGroup;
 }
+// Record of one (tile, Gaussian) pair in pair_grad: (S1, Sx, Sy, Sxx, Sxy, Syy, Rr, Rg, Rb, Rd), 40 B,
+// no padding: k_preprocess_bwd streams a wave's contiguous run of records with coalesced loads.
+constexpr int kPairStride = 10;
+constexpr int kPreChunk = 128;      // records staged per wave and trip in k_preprocess_bwd (5 KB of LDS per wave)
 constexpr int kBinBlocks = 512;    // workgroups of the LDS-privatised binning passes
 constexpr int kBinSmallMap = 65536;  // up to here the binning passes run 256-thread workgroups of 256 Gaussians
 constexpr int kBinMaxTilesLds = 12288;   // T above this falls back to global atomics
@@ -174,7 +178,7 @@ inline Layout make_layout(const mgs_raster_shape& s) {
   L.ckpt = o; o = align_up(o + L.max_segs * 5 * 256 * 4);
   L.bins_bytes = o;
   o = 0;
-  L.pair_grad = o; o = align_up(o + cap * 48);
+  L.pair_grad = o; o = align_up(o + cap * kPairStride * 4);
   const uint64_t npre = (N + kPreBlock - 1) / kPreBlock;
   L.tau_partial = o; o = align_up(o + npre * 6 * 4);
   L.bwd_bytes = o;
