@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64 * G, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_
   static_assert(SKETCH || !JONLY, "JONLY is a sketch-mode variant");
   static_assert(!(SKETCH && POSE), "POSE is a plain-mode variant");
   static_assert(kSeg == 64, "one staged record per lane");
-  static_assert(G == 1 || (!SKETCH && G == kBwdGroup && kBwdChunk % G == 0), "grouped form: plain variants only");
+  static_assert(G == 1 || (!SKETCH && G == kBwdGroup && kBwdChunk % G == 0 && 4 % G == 0), "grouped form: plain variants only");
   __shared__ float4 s_r0a[G][kSeg], s_r1a[G][kSeg];
   __shared__ float2 s_r2a[G][kSeg];         // 2560 B of LDS per wave
   __shared__ float4 s_coef[SKETCH ? kSeg : 1][9];   // per splat: 6 features x 6 tau components
@@ -252,7 +252,8 @@ __global__ __launch_bounds__(64 * G, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_
       // the tile's last contribution
       const int gbase = P.seg_rec[item_first].w;
       if (tile_last > gbase) {                             // workgroup-uniform
-        const int q = wave;
+#pragma unroll
+       for (int q = wave; q < 4; q += G) {
         const int px = qx + 8 * (q & 1), py = qy + 8 * (q >> 1);
         const bool in_img = px < P.W && py < P.H;
         const size_t pix = (size_t)min(py, P.H - 1) * P.W + min(px, P.W - 1);
@@ -266,6 +267,7 @@ __global__ __launch_bounds__(64 * G, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_
         s_pg[64 * q + lane] = make_float4(a0, a1, a2, ad);
         s_pc[64 * q + lane] = make_float4(tc.y + tf * bg0, tc.z + tf * bg1, tc.w + tf * bg2, __int_as_float(dl.x));
         s_pl[64 * q + lane] = dl.y;
+       }
       }
     }
     __syncthreads();        // the ONLY workgroup barrier: every wave of the group reaches it exactly once
@@ -371,8 +373,7 @@ __global__ __launch_bounds__(64 * G, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_
   unsigned long long mq[4] = {0ull, 0ull, 0ull, 0ull};
   unsigned long long written = 0ull;
   // one splat: (u, v, bd2) = its staged record; mq = the quadrants the segment's splats reach
-  auto visit = [&](int j, const float4 u, const float4 v) {
-    const float2 bd2 = s_r2[j];        // (b, depth): needed late in the visit, not worth two prefetch registers
+  auto visit = [&](int j, const float4 u, const float4 v, const float2 bd2) {
     const v2f mu = v2f{u.x, u.y} - P0, RG = {v.z, v.w}, BD = {bd2.x, bd2.y};
     const int idx = sub_base + j;
     const v2f* cf2 = reinterpret_cast<const v2f*>(&s_coef[SKETCH ? j : 0][0]);   // [feature][tau pair]
@@ -515,18 +516,20 @@ __global__ __launch_bounds__(64 * G, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_
       if (todo != 0ull) {
         int j0 = __builtin_ctzll(todo);
         float4 u0 = s_r0[j0], v0 = s_r1[j0];
+        float2 w0 = s_r2[j0];
         while (true) {
           todo &= todo - 1ull;
           const int j1 = __builtin_ctzll(todo) & 63;       // todo == 0: harmless read of slot 63
           const float4 u1 = s_r0[j1], v1 = s_r1[j1];
+          const float2 w1 = s_r2[j1];
           __builtin_amdgcn_sched_barrier(0);               // keep the prefetch above the arithmetic
-          visit(j0, u0, v0);
+          visit(j0, u0, v0, w0);
           if (todo == 0ull) break;
           todo &= todo - 1ull;
           j0 = __builtin_ctzll(todo) & 63;
-          u0 = s_r0[j0]; v0 = s_r1[j0];
+          u0 = s_r0[j0]; v0 = s_r1[j0]; w0 = s_r2[j0];
           __builtin_amdgcn_sched_barrier(0);
-          visit(j1, u1, v1);
+          visit(j1, u1, v1, w1);
           if (todo == 0ull) break;
         }
       }
@@ -922,11 +925,11 @@ int launch_backward(const KP& P, const KB& B, hipStream_t st, bool skip_tau_redu
     if (B.sketch_only) return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
   } else {
     if (B.g_means3D || B.map.on)
-      launch("blend_bwd", k_blend_bwd<false, false, false, kBwdGroup>, dim3(grid_pad(P.max_segs, kBwdChunk) / kBwdGroup),
-             dim3(64 * kBwdGroup), st, P, B);
+      launch_smem("blend_bwd", k_blend_bwd<false, false, false, kBwdGroup>, dim3(grid_pad(P.max_segs, kBwdChunk) / kBwdGroup),
+                  dim3(64 * kBwdGroup), kBwdLdsPad, st, P, B);
     else   // pose-only (tracking)
-      launch("blend_bwd", k_blend_bwd<false, false, true, kBwdGroup>, dim3(grid_pad(P.max_segs, kBwdChunk) / kBwdGroup),
-             dim3(64 * kBwdGroup), st, P, B);
+      launch_smem("blend_bwd", k_blend_bwd<false, false, true, kBwdGroup>, dim3(grid_pad(P.max_segs, kBwdChunk) / kBwdGroup),
+                  dim3(64 * kBwdGroup), kBwdLdsPad, st, P, B);
   }
   const int npre = (P.N + kPreBlock - 1) / kPreBlock;
   if (B.map.on && P.deg == 0) launch("preprocess_bwd_map", k_preprocess_bwd<true, true>, dim3(npre), dim3(kPreBlock), st, P, B);

@@ -72,6 +72,7 @@ int fill_kp(const mgs_forward_args& a, bool need_bins, bool need_outputs, KP& P)
   P.pair_off = (int*)(g + L.pair_off);
   P.block_prefix = (int*)(g + L.block_prefix);
   P.scan_tmp = (int*)(g + L.scan_tmp);
+  P.hit_mask = (unsigned int*)(g + L.hit_mask);
   P.tile_count = (int*)(g + L.tile_count);
   P.tile_offset = (int*)(g + L.tile_offset);
   P.tile_cursor = (int*)(g + L.tile_cursor);

@@ -23,6 +23,8 @@ struct KP {
   int* pair_off;           // N: slot offset of the Gaussian's first pair inside its binning block
   int* block_prefix;       // kBinBlocks+1: exclusive scan of the blocks' pair totals
   int* scan_tmp;           // scratch of the fallback N-scan
+  unsigned int* hit_mask;  // N: which tiles of a small rectangle (<= kBinSmallRect, row-major bit i) the count pass
+                           // found reachable - the emit pass replays the bits instead of the exact tests
   int* tile_count;
   int* tile_offset;
   int* tile_cursor;
@@ -99,7 +101,7 @@ constexpr uint64_t kAlign = 256;
 inline uint64_t align_up(uint64_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
 
 struct Layout {
-  uint64_t rec, pair_count, pair_off, block_prefix, scan_tmp, tile_count, tile_offset, tile_cursor, bin_table, final_TC, final_DL,
+  uint64_t rec, pair_count, pair_off, hit_mask, block_prefix, scan_tmp, tile_count, tile_offset, tile_cursor, bin_table, final_TC, final_DL,
       quad_last, seg_offset, counters, geom_bytes;
   uint64_t keys, payload, seg_rec, ckpt, max_segs, bins_bytes;
   uint64_t pair_grad, tau_partial, bwd_bytes;
@@ -129,7 +131,16 @@ constexpr int kItem = 32;
 // depth, list lengths) through LDS - loaded once per workgroup instead of once per item.  The
 // forward pads every tile's item count to a multiple of kBwdGroup (empty items: 0 splats), so a
 // workgroup never straddles two tiles.
-constexpr int kBwdGroup = 4;
+// (Tuning builds may override the two constants below with -DMGS_TUNE_BWD_GROUP=1|2|4 and
+// -DMGS_TUNE_BWD_LDS_PAD=<bytes>: extra dynamic LDS per workgroup caps the workgroups resident on a CU.)
+#ifndef MGS_TUNE_BWD_GROUP
+#define MGS_TUNE_BWD_GROUP 1
+#endif
+#ifndef MGS_TUNE_BWD_LDS_PAD
+#define MGS_TUNE_BWD_LDS_PAD 0
+#endif
+constexpr int kBwdGroup = MGS_TUNE_BWD_GROUP;
+constexpr int kBwdLdsPad = MGS_TUNE_BWD_LDS_PAD;
 __host__ __device__ inline int items_of_tile(int pairs) {
   return ((pairs + kItem - 1) / kItem + kBwdGroup - 1) / kBwdGroup * kBwdGroup;
 }
@@ -155,6 +166,7 @@ inline Layout make_layout(const mgs_raster_shape& s) {
   L.rec = o; o = align_up(o + N * sizeof(SplatRec));
   L.pair_count = o; o = align_up(o + N * 4);
   L.pair_off = o; o = align_up(o + N * 4);
+  L.hit_mask = o; o = align_up(o + N * 4);
   L.block_prefix = o; o = align_up(o + (uint64_t)(kBinBlocks + 1) * 4);
   {
     const uint64_t nscan = (N + kScanBlock - 1) / kScanBlock + 1;

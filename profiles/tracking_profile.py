@@ -1,0 +1,78 @@
+"""Per-kernel times of the native tracking iterations (row a12) on the GPU box:
+
+    python profiles/tracking_profile.py [gaussians ...]      # default: 300000 8000
+
+For every map size: wall time per iteration of NativeTracker.step() (first order) and
+step_second_order() (sketched LM), and the per-kernel averages from the library's own HIP-event
+log (mgs_profile_enable / mgs_profile_read: events on the launch stream).  SYN-C-shaped frozen map
+at 640x480 (fr3_office intrinsics), target = a render of the same map from the identity pose."""
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from monogs_amd import _cabi, synthetic as S  # noqa: E402
+from monogs_amd.gaussian_renderer import render  # noqa: E402
+from monogs_amd.pose import SE3_exp  # noqa: E402
+from monogs_amd.slam_loops import GaussianParams, Pipe, ViewCamera  # noqa: E402
+from monogs_amd.tracking_native import NativeTracker  # noqa: E402
+
+
+def profile(step, warm, timed, prof):
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(timed):
+        step()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / timed * 1e6
+    _cabi.profile_enable(True)
+    for _ in range(prof):
+        step()
+    torch.cuda.synchronize()
+    p = _cabi.profile_read()
+    _cabi.profile_enable(False)
+    k = {n: v[0] / v[1] * 1e3 for n, v in p.items()}
+    return wall, k
+
+
+def main():
+    dev = torch.device("cuda:0")
+    sizes = [int(a) for a in sys.argv[1:]] or [300000, 8000]
+    for N in sizes:
+        sc = S.make_scene(N, 640, 480, seed=0)
+        cam = sc.cam
+        H, W = cam.H, cam.W
+        gauss = GaussianParams(sc.means3D.to(dev), sc.log_scales.to(dev), sc.rot.to(dev), sc.opacity_logit.to(dev),
+                               sc.features_dc.to(dev))
+        fovx, fovy = 2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy)
+        bg = torch.zeros(3, device=dev)
+
+        def view(T):
+            return ViewCamera(1, torch.zeros(3, H, W), T, cam.projmatrix_raw, fovx, fovy, H, W, dev)
+        with torch.no_grad():
+            target = render(view(torch.eye(4)), gauss, Pipe, bg)["render"].clone()
+        vp = view(SE3_exp(torch.tensor([0.01, -0.008, 0.006, 0.002, -0.003, 0.002])))
+        vp.original_image = target
+        vp.rgb_pixel_mask_mapping = (target.sum(0) > 0.01).view(1, H, W)
+        trk = NativeTracker(vp, gauss, bg)
+        trk.args.adam.sticky_converged = 0        # keep stepping after convergence: this is a timing run
+        wall, k = profile(trk.step, 20, 400, 50)
+        print(f"{N} Gaussians @ {W}x{H}, D = {trk.pairs()}: first order {wall:.1f} us / iteration "
+              f"({1e6 / wall:.0f} its/s), kernels {sum(k.values()):.1f} us:",
+              {n: round(v, 1) for n, v in sorted(k.items(), key=lambda kv: -kv[1])})
+        trk.enable_second_order(stack_dim=16, sketch_dim=64, initial_lambda=1e-3)
+        wall, k = profile(trk.step_second_order, 10, 200, 30)
+        print(f"{N} Gaussians @ {W}x{H}: second order (stack 16, sketch 64) {wall:.1f} us / iteration "
+              f"({1e6 / wall:.0f} its/s), kernels {sum(k.values()):.1f} us:",
+              {n: round(v, 1) for n, v in sorted(k.items(), key=lambda kv: -kv[1])})
+        assert trk.check_capacity()
+
+
+if __name__ == "__main__":
+    main()

@@ -219,11 +219,17 @@ def test_native_mapper_sharded_at_the_config5_shape(built):
     for k in ("xyz", "opacity", "scaling", "ids", "n_obs"):
         assert np.array_equal(r0[k], r1[k]), k
     assert single["n_mid"] == r0["n_mid"] and single["n"] == r0["n"] and single["n_mid"] != 50000
-    assert np.array_equal(single["ids"].numpy(), r0["ids"]) and np.array_equal(single["n_obs"].numpy(), r0["n_obs"])
+    assert np.array_equal(single["ids"].numpy(), r0["ids"])
+    # n_obs counts views with n_touched > 0, and n_touched counts contributions with T (1 - alpha) > 0.5: a
+    # threshold in fp32.  The single process adds the views' gradients in another order than the two
+    # ranks do (a + b + c ... vs (a + c ...) + (b + d ...)), so after four Adam steps a borderline
+    # Gaussian among the 8 x 19 k (view, Gaussian) verdicts may fall on the other side
+    assert (single["n_obs"].numpy() == r0["n_obs"]).mean() > 0.999
     for k, tol in (("xyz", 2e-4), ("opacity", 5e-3), ("scaling", 2e-4)):
         close = (np.abs(single[k].numpy() - r0[k]) <= tol).mean()
         assert close > 0.995, (k, close)
-    assert abs(single["loss"] - r0["loss"]) <= 1e-4 * abs(single["loss"])
+    # the loss scalar is rank-local (this rank's views): the two shards add up to the window's objective
+    assert abs(single["loss"] - (r0["loss"] + r1["loss"])) <= 1e-3 * abs(single["loss"])
     for uid in range(10):
         assert np.array_equal(r0[f"T{uid}"], r1[f"T{uid}"]) and r0[f"a{uid}"] == r1[f"a{uid}"], uid
         assert np.allclose(r0[f"T{uid}"], single[f"T{uid}"].numpy(), atol=5e-5), uid

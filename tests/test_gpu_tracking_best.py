@@ -129,10 +129,14 @@ def test_native_two_phase_run_matches_the_python_loop(built):
     vp, _ = _frame(view, gauss, dev, 3, T0)
     pkg, best_p, it_p, n_p = track_frame(vp, gauss, bg, first_order_iters=fo, second_order_iters=so, config=cfg,
                                          stack_dim=stack, sketch_dim=sketch, fsa_fn=fsa_fn)
-    assert n == n_p == fo + so
+    # the second order may converge (|x| < 1e-5) before its budget: the Python loop then stops at once, the
+    # native run at its next read-back of the sticky flag (the iterations in between change nothing)
+    assert fo < n_p <= n <= fo + so
     print('best iterate', it_p, 'of', fo, '+', so, 'L1', best_p)
     assert trk.best_iteration() == it_p
-    assert abs(trk.best_loss.item() - best_p) <= 5e-3 * best_p
+    # at the optimum the residual is ~1e-4 of the initial one (the target is a render of the same map): the
+    # two paths' rounding shows in what is left, so the tolerance is tied to the initial residual as well
+    assert abs(trk.best_loss.item() - best_p) <= 5e-3 * best_p + 1e-4 * l1s[0]
     assert torch.allclose(vn.T, vp.T, atol=5e-4)
     assert torch.allclose(vn.exposure_a, vp.exposure_a, atol=5e-4)
     err0 = (T0 - torch.eye(4)).abs().max().item()
