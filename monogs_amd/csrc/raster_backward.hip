@@ -93,45 +93,29 @@ constexpr float kLog2eB = 1.4426950408889634f;
 // not formed and six values instead of ten are reduced per splat.
 
 // Orders this wave's LDS writes before its own later LDS reads (the staged records belong to one
-// wave: no workgroup barrier is wanted, and in a multi-wave workgroup none may be used where the
-// waves' control flow differs).  LDS operations of one wave execute in order; the waitcnt + memory
-// clobber keep the compiler from moving accesses across.
+// wave: no workgroup barrier is wanted).  LDS operations of one wave execute in order; the waitcnt +
+// memory clobber keep the compiler from moving accesses across.
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-// G = waves (= consecutive items of one tile) per workgroup.  G == 1: every item loads the per-pixel
-// state of its tile itself (sketch variants).  G == kBwdGroup (plain / POSE): the forward padded every
-// tile's item count to a multiple of G, so the G items of a workgroup belong to ONE tile; wave w loads
-// quadrant w of the tile's per-pixel state (upstream gradients, final colour + background, final
-// depth, list length: 9 dwords per pixel) into LDS ONCE per workgroup, and every item reads it from
-// there - only its own 5-KB checkpoint still comes from HBM / L2.
-template <bool SKETCH, bool JONLY = false, bool POSE = false, int G = 1>
-__global__ __launch_bounds__(64 * G, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(KP P, KB B) {
+template <bool SKETCH, bool JONLY = false, bool POSE = false>
+__global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(KP P, KB B) {
   MGS_BSTAMP;
   static_assert(SKETCH || !JONLY, "JONLY is a sketch-mode variant");
   static_assert(!(SKETCH && POSE), "POSE is a plain-mode variant");
   static_assert(kSeg == 64, "one staged record per lane");
-  static_assert(G == 1 || (!SKETCH && G == kBwdGroup && kBwdChunk % G == 0 && 4 % G == 0), "grouped form: plain variants only");
-  __shared__ float4 s_r0a[G][kSeg], s_r1a[G][kSeg];
-  __shared__ float2 s_r2a[G][kSeg];         // 2560 B of LDS per wave
+  __shared__ float4 s_r0[kSeg], s_r1[kSeg];
+  __shared__ float2 s_r2[kSeg];             // 2560 B of LDS in all
   __shared__ float4 s_coef[SKETCH ? kSeg : 1][9];   // per splat: 6 features x 6 tau components
-  // grouped form: the tile's per-pixel state, quadrant-major (entry 64 q + lane), 9 KB
-  __shared__ float4 s_pg[G > 1 ? 256 : 1];   // (dL/dC0, dL/dC1, dL/dC2, dL/dD), zero outside the image
-  __shared__ float4 s_pc[G > 1 ? 256 : 1];   // (C_final + T_final bg) x 3, D_final
-  __shared__ int s_pl[G > 1 ? 256 : 1];      // n_contrib
-  const int wave = G > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;     // wave-uniform: an SGPR
-  float4* const s_r0 = s_r0a[wave];
-  float4* const s_r1 = s_r1a[wave];
-  float2* const s_r2 = s_r2a[wave];
   // Sketch mode: a workgroup takes kSketchReps consecutive items (mostly of one tile) and adds its
   // per-pixel Jacobian rows to pix_jac once per tile instead of once per item: the atomics, not the
   // walk, bound that variant, and the 32-splat items doubled them.
   constexpr int kReps = SKETCH ? kSketchReps : 1;
   const int n_items = min(P.seg_offset[P.T], P.max_segs);
-  int item_first = xcd_remap<kBwdChunk / G>(blockIdx.x) * kReps * G;
-  const int lane = threadIdx.x & 63;
+  int item_first = xcd_remap<kBwdChunk>(blockIdx.x) * kReps;
+  const int lane = threadIdx.x;
   MGS_BORDER(item_first, SKETCH);
   if (item_first < 0) return;
-  if (item_first >= n_items) return;        // workgroup-uniform
+  if (item_first >= n_items) return;
   // sketch mode: per-pixel pose-Jacobian rows, as pairs (tau 0,1) (2,3) (4,5), of the tile in hand
   v2f J2[SKETCH ? 4 : 1][3];
 #pragma unroll
@@ -164,26 +148,15 @@ __global__ __launch_bounds__(64 * G, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_
     }
   };
   for (int rep = 0; rep < kReps; rep++) {
-  const int item = item_first + rep + wave;
+  const int item = item_first + rep;
+  if (item >= n_items) break;
+  if (rep > 0) wave_lds_fence();     // orders the reuse of the staged records
   // One 16-B record per item (written by the tile sort) instead of a chain of dependent loads:
   // tile, index of the item's first key, number of splats (<= kItem), position in the tile's list.
-  int4 sr;
-  if constexpr (G > 1) {
-    // every wave stays until the workgroup barrier below: an item beyond the list (only possible with
-    // an undersized capacity) or a padding item has 0 splats
-    const int4 sr0 = P.seg_rec[item_first];            // the group's tile (uniform over the workgroup)
-    sr = item < n_items ? P.seg_rec[item] : make_int4(sr0.x, 0, 0, 0x7fffffff);
-    sr.x = sr0.x;
-  } else {
-    if (item >= n_items) break;
-    if (rep > 0) wave_lds_fence();     // orders the reuse of the staged records
-    sr = P.seg_rec[item];
-  }
+  const int4 sr = P.seg_rec[item];
   const int tile = sr.x, k0 = sr.y, nb = sr.z, base = sr.w;
   MGS_BITEM(item, base);
-  if constexpr (G == 1) {
-    if (nb <= 0) continue;
-  }
+  if (nb <= 0) continue;
   if constexpr (SKETCH) {
     if (tile != jtile) { flush_jacobian(); jtile = tile; }
   }
@@ -208,7 +181,7 @@ __global__ __launch_bounds__(64 * G, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_
   unsigned int lastp = 0u;
   float g0[4], g1[4], g2[4], gd[4], T[4], gS[4];
   const float bg0 = P.bg[0], bg1 = P.bg[1], bg2 = P.bg[2];
-  const float* ck = (base > 0 && nb > 0) ? P.ckpt + (size_t)item * (5 * 256) : nullptr;
+  const float* ck = (base > 0) ? P.ckpt + (size_t)item * (5 * 256) : nullptr;
   // Last list position that still contributes anywhere in each quadrant (stored by the forward's
   // quadrant waves; a quadrant outside the image was never rendered).  A splat behind it cannot
   // contribute in that quadrant - the forward had stopped visiting the saturated quadrant - so its
@@ -229,65 +202,6 @@ __global__ __launch_bounds__(64 * G, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_
     T[q] = 0.f;
     gS[q] = 0.f;
   }
-  if constexpr (G > 1) {
-    // ---- grouped form: the tile's per-pixel state once per workgroup, through LDS -----------------
-    // The item's own checkpoint is requested FIRST (it does not depend on the shared state), so that
-    // it is in flight together with the shared loads: still one memory round trip per item.
-    const bool mine = nb > 0 && tile_last > base;        // wave-uniform
-    float4 k4[4];
-    float k3[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < 4; q++) k4[q] = make_float4(1.f, 0.f, 0.f, 0.f);
-    if (mine && ck) {
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int p = 64 * q + lane;
-        k4[q] = reinterpret_cast<const float4*>(ck)[p];
-        k3[q] = ck[1024 + p];
-      }
-    }
-    {
-      // wave w brings in quadrant w (also when its own item is empty: the others may need it); the
-      // group's first item has the smallest base, so nothing is needed if even that one lies behind
-      // the tile's last contribution
-      const int gbase = P.seg_rec[item_first].w;
-      if (tile_last > gbase) {                             // workgroup-uniform
-#pragma unroll
-       for (int q = wave; q < 4; q += G) {
-        const int px = qx + 8 * (q & 1), py = qy + 8 * (q >> 1);
-        const bool in_img = px < P.W && py < P.H;
-        const size_t pix = (size_t)min(py, P.H - 1) * P.W + min(px, P.W - 1);
-        const size_t qi = (size_t)tile * 256 + 64 * q + lane;     // quadrant-major: coalesced
-        const int2 dl = P.final_DL[qi];
-        float a0 = B.grad_color[pix], a1 = B.grad_color[HW + pix], a2 = B.grad_color[2 * HW + pix];
-        float ad = B.grad_depth ? B.grad_depth[pix] : 0.f;
-        const float4 tc = P.final_TC[qi];
-        if (!in_img) { a0 = 0.f; a1 = 0.f; a2 = 0.f; ad = 0.f; }
-        const float tf = tc.x;
-        s_pg[64 * q + lane] = make_float4(a0, a1, a2, ad);
-        s_pc[64 * q + lane] = make_float4(tc.y + tf * bg0, tc.z + tf * bg1, tc.w + tf * bg2, __int_as_float(dl.x));
-        s_pl[64 * q + lane] = dl.y;
-       }
-      }
-    }
-    __syncthreads();        // the ONLY workgroup barrier: every wave of the group reaches it exactly once
-    if (nb <= 0) return;    // padding item / beyond the list
-    if (mine) {
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const float4 pg = s_pg[64 * q + lane], pc = s_pc[64 * q + lane];
-        const int ln_q = s_pl[64 * q + lane];
-        g0[q] = pg.x; g1[q] = pg.y; g2[q] = pg.z; gd[q] = pg.w;
-        const float c0 = pc.x - k4[q].y, c1 = pc.y - k4[q].z, c2 = pc.z - k4[q].w, cd = pc.w - k3[q];
-        const float gs = g0[q] * c0 + g1[q] * c1 + g2[q] * c2 + gd[q] * cd;
-        const bool on = qlast[q] > base && ln_q > base;       // as in the ungrouped form below
-        lastp |= (unsigned int)min(max((qlast[q] > base ? ln_q : 0) - base, 0), 255) << (8 * q);
-        T[q] = on ? k4[q].x : 0.f;
-        gS[q] = on ? gs : 0.f;
-        if (qlast[q] <= base) { g0[q] = 0.f; g1[q] = 0.f; g2[q] = 0.f; gd[q] = 0.f; }
-      }
-    }
-  } else {
   if (tile_last > base) {      // wave-uniform; an item behind the tile's last contribution loads nothing
     // All loads of the four quadrants are issued back to back, branch-free (addresses of pixels
     // outside the image are clamped, quadrants that are already saturated are loaded anyway and
@@ -338,9 +252,6 @@ __global__ __launch_bounds__(64 * G, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_
       gS[q] = on ? gs : 0.f;
       if (qlast[q] <= base) { g0[q] = 0.f; g1[q] = 0.f; g2[q] = 0.f; gd[q] = 0.f; }
     }
-  }
-
-
   }
 
   MGS_BMARK(0);
@@ -925,11 +836,9 @@ int launch_backward(const KP& P, const KB& B, hipStream_t st, bool skip_tau_redu
     if (B.sketch_only) return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
   } else {
     if (B.g_means3D || B.map.on)
-      launch_smem("blend_bwd", k_blend_bwd<false, false, false, kBwdGroup>, dim3(grid_pad(P.max_segs, kBwdChunk) / kBwdGroup),
-                  dim3(64 * kBwdGroup), kBwdLdsPad, st, P, B);
+      launch("blend_bwd", k_blend_bwd<false>, dim3(grid_pad(P.max_segs, kBwdChunk)), dim3(64), st, P, B);
     else   // pose-only (tracking)
-      launch_smem("blend_bwd", k_blend_bwd<false, false, true, kBwdGroup>, dim3(grid_pad(P.max_segs, kBwdChunk) / kBwdGroup),
-                  dim3(64 * kBwdGroup), kBwdLdsPad, st, P, B);
+      launch("blend_bwd", k_blend_bwd<false, false, true>, dim3(grid_pad(P.max_segs, kBwdChunk)), dim3(64), st, P, B);
   }
   const int npre = (P.N + kPreBlock - 1) / kPreBlock;
   if (B.map.on && P.deg == 0) launch("preprocess_bwd_map", k_preprocess_bwd<true, true>, dim3(npre), dim3(kPreBlock), st, P, B);

@@ -338,8 +338,7 @@ __global__ __launch_bounds__(256) void k_scan_write(KP P) {
 
 // ---------------------------------------------------------------------------------
 // Exclusive scans of the T tile counts (-> tile_offset, D) and of the per-tile segment
-// backward item counts items_of_tile(n_t) = ceil(n_t / kItem) padded to kBwdGroup (-> seg_offset) by one
-// 1024-thread workgroup.
+// backward item counts ceil(n_t / kItem) (-> seg_offset) by one 1024-thread workgroup.
 __device__ __forceinline__ void tile_scan_body(const KP& P, int nbin, int* s_sum, int* s_seg) {
   // Three exclusive scans over the 1024 threads at once (binning-block totals, tile pair counts,
   // tile item counts) + the largest tile: inclusive scans inside each wave with shuffles, the sixteen
@@ -353,7 +352,7 @@ __device__ __forceinline__ void tile_scan_body(const KP& P, int nbin, int* s_sum
   for (int i = lo; i < hi; i++) {
     const int c = __hip_atomic_load(&P.tile_count[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     local += c;
-    lseg += items_of_tile(c);
+    lseg += (c + kItem - 1) / kItem;
     lmax = max(lmax, c);
   }
   int ib = vb, ip = local, is = lseg;
@@ -386,7 +385,7 @@ __device__ __forceinline__ void tile_scan_body(const KP& P, int nbin, int* s_sum
     P.tile_offset[i] = run;
     P.seg_offset[i] = rseg;
     run += c;
-    rseg += items_of_tile(c);
+    rseg += (c + kItem - 1) / kItem;
   }
   if (tid == 1023) {
     P.tile_offset[P.T] = tot_p;
@@ -606,7 +605,7 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(KP P) {
   if (MIN_N == 0) {   // item -> tile map for the item-parallel backward
     // EVERY item the scan counted gets a record - also those cut off by an undersized pair
     // capacity (0 splats), so that the backward never reads an unwritten record
-    const int s0 = P.seg_offset[tile], ns = items_of_tile(n_all);      // incl. the padding items (0 splats)
+    const int s0 = P.seg_offset[tile], ns = (n_all + kItem - 1) / kItem;
     for (int i = tid; i < ns; i += THREADS)
       if (s0 + i < P.max_segs)
         P.seg_rec[s0 + i] = make_int4(tile, min(start + i * kItem, P.cap), max(0, min(kItem, n - i * kItem)), i * kItem);
@@ -667,7 +666,7 @@ __global__ __launch_bounds__(256) void k_tile_sort_reg(KP P) {
   {   // item -> tile map for the item-parallel backward
     // EVERY item the scan counted gets a record - also those cut off by an undersized pair
     // capacity (0 splats), so that the backward never reads an unwritten record
-    const int s0 = P.seg_offset[tile], ns = items_of_tile(n_all);      // incl. the padding items (0 splats)
+    const int s0 = P.seg_offset[tile], ns = (n_all + kItem - 1) / kItem;
     for (int i = tid; i < ns; i += 256)
       if (s0 + i < P.max_segs)
         P.seg_rec[s0 + i] = make_int4(tile, min(start + i * kItem, P.cap), max(0, min(kItem, n - i * kItem)), i * kItem);

@@ -126,24 +126,6 @@ constexpr int kSeg = 64;            // splats staged at a time by the blend kern
 // round of items, which run two or three to a SIMD at the latency of a lone wave; shorter items make
 // that round shorter, at the price of a second per-pixel state load and checkpoint per segment.
 constexpr int kItem = 32;
-// Items per workgroup of the plain blend backward: kBwdGroup consecutive items of ONE tile run as the
-// waves of one workgroup and share the tile's per-pixel state (upstream gradients, final colour /
-// depth, list lengths) through LDS - loaded once per workgroup instead of once per item.  The
-// forward pads every tile's item count to a multiple of kBwdGroup (empty items: 0 splats), so a
-// workgroup never straddles two tiles.
-// (Tuning builds may override the two constants below with -DMGS_TUNE_BWD_GROUP=1|2|4 and
-// -DMGS_TUNE_BWD_LDS_PAD=<bytes>: extra dynamic LDS per workgroup caps the workgroups resident on a CU.)
-#ifndef MGS_TUNE_BWD_GROUP
-#define MGS_TUNE_BWD_GROUP 1
-#endif
-#ifndef MGS_TUNE_BWD_LDS_PAD
-#define MGS_TUNE_BWD_LDS_PAD 0
-#endif
-constexpr int kBwdGroup = MGS_TUNE_BWD_GROUP;
-constexpr int kBwdLdsPad = MGS_TUNE_BWD_LDS_PAD;
-__host__ __device__ inline int items_of_tile(int pairs) {
-  return ((pairs + kItem - 1) / kItem + kBwdGroup - 1) / kBwdGroup * kBwdGroup;
-}
 // Record of one (tile, Gaussian) pair in pair_grad: (S1, Sx, Sy, Sxx, Sxy, Syy, Rr, Rg, Rb, Rd), 40 B,
 // no padding: k_preprocess_bwd streams a wave's contiguous run of records with coalesced loads.
 constexpr int kPairStride = 10;
@@ -185,7 +167,7 @@ inline Layout make_layout(const mgs_raster_shape& s) {
   o = 0;
   L.keys = o; o = align_up(o + cap * 8);
   L.payload = o; o = align_up(o + cap * 4);
-  L.max_segs = cap / kItem + (uint64_t)kBwdGroup * T;     // ceil(n_t / kItem) padded to a multiple of kBwdGroup per tile
+  L.max_segs = cap / kItem + T;
   L.seg_rec = o; o = align_up(o + L.max_segs * 16);
   L.ckpt = o; o = align_up(o + L.max_segs * 5 * 256 * 4);
   L.bins_bytes = o;
