@@ -34,6 +34,8 @@ def _model_from_scene(sc, dev):
 
 
 FROZEN_POSE_LR = {"cam_rot_delta": 0.0, "cam_trans_delta": 0.0, "exposure_a": 0.0, "exposure_b": 0.0}
+# (densification is switched off as well - "gaussian_update_every" 1e9 with an offset that is never hit; the
+# default offset of 50 would densify + prune at iteration 50 and leave a different, much smaller map)
 
 
 def _spread(rates):
@@ -76,7 +78,7 @@ def bench_mapping(sc, dev, iters: int = 100, repeats: int = 3):
                     gm.max_radii2D = torch.maximum(gm.max_radii2D, o[3].float())
         else:
             lanes = {"native_1_stream": 1, "native": 2, "native_3_streams": 3}[mode]
-            mp = NativeMapper(gm, bg, config={"Training": {"gaussian_update_every": 10 ** 9, "gaussian_reset": 10 ** 9,
+            mp = NativeMapper(gm, bg, config={"Training": {"gaussian_update_every": 10 ** 9, "gaussian_update_offset": 10 ** 9 - 1, "gaussian_reset": 10 ** 9,
                                                            "lr": FROZEN_POSE_LR}}, concurrent_views=lanes)
             for i, v in enumerate(views):
                 mp.add_keyframe(i, v)
@@ -99,6 +101,8 @@ def bench_mapping(sc, dev, iters: int = 100, repeats: int = 3):
         out[f"{mode}_ms_per_view"] = round(1e3 / sp["median"] / 10, 4)
         if mode.startswith("native") and not mp.check_capacity():
             raise RuntimeError("native mapping bench overflowed its pair capacity")
+        if len(gm) != N:
+            raise RuntimeError(f"mapping bench: the map changed size ({N} -> {len(gm)}): not the stated workload")
     return out
 
 
@@ -125,7 +129,7 @@ def bench_mapping_sharded(dev, rank: int, world: int, backend, n_gaussians: int 
     gm = _model_from_scene(sc, dev)
     views = [ViewCamera(i, sc.gt_image, view_pose(i), cam.projmatrix_raw, fovx, fovy, H, W, dev, gt_depth=sc.gt_depth,
                         intrinsics=(cam.fx, cam.fy, cam.cx, cam.cy)) for i in range(10)]
-    mp = NativeMapper(gm, bg, config={"Training": {"monocular": False, "window_size": 8, "gaussian_update_every": 10 ** 9,
+    mp = NativeMapper(gm, bg, config={"Training": {"monocular": False, "window_size": 8, "gaussian_update_every": 10 ** 9, "gaussian_update_offset": 10 ** 9 - 1,
                                                    "gaussian_reset": 10 ** 9, "lr": FROZEN_POSE_LR}})
     for i, v in enumerate(views):
         mp.add_keyframe(i, v)
@@ -154,6 +158,8 @@ def bench_mapping_sharded(dev, rank: int, world: int, backend, n_gaussians: int 
         barrier()
         rates.append(iters / max_over_ranks(time.perf_counter() - t0))
     ok = mp.check_capacity()
+    if len(gm) != n_gaussians:
+        raise RuntimeError(f"sharded mapping bench: the map changed size ({n_gaussians} -> {len(gm)})")
     mp.timing = []
     mp.map(window, iters=profile_iters)
     ts = mp.timing_summary()

@@ -314,6 +314,8 @@ __global__ __launch_bounds__(kLossBlock) void k_track_loss_bwd_finish(mgs_tracki
 // One pass (mgs_tracking_loss_onepass): block sums of h^2, the image gradient and the exposure
 // partials WITHOUT the 1 / loss factor of the norm's derivative; k_pose_adam_update applies it
 // (loss_norm_mode).  partial = [n] sum h^2 | [n] d/da | [n] d/db | [n] sum |r| (before Huber).
+// VEC: four consecutive pixels per thread and trip through 16-B loads / stores (as k_map_loss_fused<true>).
+template <bool VEC>
 __global__ __launch_bounds__(kLossBlock) void k_track_loss_onepass(mgs_tracking_loss_args A) {
   __shared__ float s_red[kLossBlock / 64];
   const float a = A.exposure_a[0];
@@ -321,20 +323,48 @@ __global__ __launch_bounds__(kLossBlock) void k_track_loss_onepass(mgs_tracking_
   const float sgn = a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f);
   const size_t HW = (size_t)A.num_pixels;
   float acc = 0.f, ga = 0.f, gb = 0.f, l1 = 0.f;
-  for (size_t p = (size_t)blockIdx.x * kLossBlock + threadIdx.x; p < HW; p += (size_t)gridDim.x * kLossBlock) {
-    const float om = A.opacity[p] * (A.mask ? A.mask[p] : 1.f);
+  auto sample = [&](float om, float im, float gt) {      // one colour sample: sums + d/d image
+    float dh;
+    const float r = om * (gain * im + bias - gt);
+    l1 += fabsf(r);
+    const float h = huber(r, A.huber_delta, dh);
+    acc += h * h;
+    const float gr = h * dh * om;
+    ga += gr * im;
+    gb += gr;
+    return gr * gain;
+  };
+  if constexpr (VEC) {
+    const size_t Q = HW / 4;
+    for (size_t q = (size_t)blockIdx.x * kLossBlock + threadIdx.x; q < Q; q += (size_t)gridDim.x * kLossBlock) {
+      float4 om = reinterpret_cast<const float4*>(A.opacity)[q];
+      if (A.mask) {
+        const float4 m = reinterpret_cast<const float4*>(A.mask)[q];
+        om.x *= m.x; om.y *= m.y; om.z *= m.z; om.w *= m.w;
+      }
+      float4 im[3], gt[3], g[3];
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-      const float im = A.image[c * HW + p];
-      float dh;
-      const float r = om * (gain * im + bias - A.gt[c * HW + p]);
-      l1 += fabsf(r);
-      const float h = huber(r, A.huber_delta, dh);
-      acc += h * h;
-      const float gr = h * dh * om;
-      A.grad_image[c * HW + p] = gr * gain;
-      ga += gr * im;
-      gb += gr;
+      for (int c = 0; c < 3; c++) {
+        im[c] = reinterpret_cast<const float4*>(A.image + c * HW)[q];
+        gt[c] = reinterpret_cast<const float4*>(A.gt + c * HW)[q];
+      }
+      // pixel by pixel, channel by channel: the per-pixel order of additions of the scalar form
+#pragma unroll
+      for (int c = 0; c < 3; c++) g[c].x = sample(om.x, im[c].x, gt[c].x);
+#pragma unroll
+      for (int c = 0; c < 3; c++) g[c].y = sample(om.y, im[c].y, gt[c].y);
+#pragma unroll
+      for (int c = 0; c < 3; c++) g[c].z = sample(om.z, im[c].z, gt[c].z);
+#pragma unroll
+      for (int c = 0; c < 3; c++) g[c].w = sample(om.w, im[c].w, gt[c].w);
+#pragma unroll
+      for (int c = 0; c < 3; c++) reinterpret_cast<float4*>(A.grad_image + c * HW)[q] = g[c];
+    }
+  } else {
+    for (size_t p = (size_t)blockIdx.x * kLossBlock + threadIdx.x; p < HW; p += (size_t)gridDim.x * kLossBlock) {
+      const float om = A.opacity[p] * (A.mask ? A.mask[p] : 1.f);
+#pragma unroll
+      for (int c = 0; c < 3; c++) A.grad_image[c * HW + p] = sample(om, A.image[c * HW + p], A.gt[c * HW + p]);
     }
   }
   const float t = block_sum(acc, s_red);
@@ -932,8 +962,16 @@ int32_t mgs_tracking_loss_onepass(const mgs_tracking_loss_args* a, int32_t* nblk
   if (!a || !a->image || !a->opacity || !a->gt || !a->exposure_a || !a->exposure_b || !a->partial ||
       !a->grad_image || a->num_pixels < 1)
     return MGS_ERR_BAD_ARGUMENT;
-  const int nb = loss_blocks(a->num_pixels);
-  launch("track_loss", k_track_loss_onepass, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a);
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool vec = a->num_pixels % 4 == 0 && al16(a->image) && al16(a->opacity) && al16(a->gt) && al16(a->mask) &&
+                   al16(a->grad_image);
+  int nb = loss_blocks(a->num_pixels);
+  if (vec) {
+    nb = loss_blocks(a->num_pixels / 4);
+    launch("track_loss", k_track_loss_onepass<true>, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a);
+  } else {
+    launch("track_loss", k_track_loss_onepass<false>, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a);
+  }
   if (nblk_out) *nblk_out = nb;
   return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
 }
