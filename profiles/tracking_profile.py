@@ -1,4 +1,5 @@
-"""Per-kernel times of the native tracking iterations (row a12) on the GPU box:
+"""Per-kernel times of the native tracking iterations (row a12) and of the native mapping view
+iteration (row a13) on the GPU box:
 
     python profiles/tracking_profile.py [gaussians ...]      # default: 300000 8000
 
@@ -72,6 +73,44 @@ def main():
               f"({1e6 / wall:.0f} its/s), kernels {sum(k.values()):.1f} us:",
               {n: round(v, 1) for n, v in sorted(k.items(), key=lambda kv: -kv[1])})
         assert trk.check_capacity()
+        mapping_profile(sc, dev)
+
+
+def mapping_profile(sc, dev):
+    """One view in flight (so that the events bracket one kernel at a time), window 8 + 2 old keyframes,
+    all learning rates 0 and densification off: the stationary workload of bench.py's `mapping` leg."""
+    from monogs_amd.bench_legs import FROZEN_POSE_LR, _model_from_scene
+    from monogs_amd.mapping_native import NativeMapper
+    from monogs_amd.parallel import view_pose
+    cam = sc.cam
+    H, W, N = cam.H, cam.W, sc.means3D.shape[0]
+    fovx, fovy = 2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy)
+    bg = torch.zeros(3, device=dev)
+    gm = _model_from_scene(sc, dev)
+    views = [ViewCamera(i, sc.gt_image, view_pose(i), cam.projmatrix_raw, fovx, fovy, H, W, dev) for i in range(10)]
+    mp = NativeMapper(gm, bg, config={"Training": {"gaussian_update_every": 10 ** 9, "gaussian_update_offset": 10 ** 9 - 1,
+                                                   "gaussian_reset": 10 ** 9, "lr": FROZEN_POSE_LR}}, concurrent_views=1)
+    for i, v in enumerate(views):
+        mp.add_keyframe(i, v)
+    mp.set_window(list(range(7, -1, -1)))
+    mp.map(iters=3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mp.map(iters=20)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / 20 * 1e6
+    _cabi.profile_enable(True)
+    mp.map(iters=5)
+    torch.cuda.synchronize()
+    p = _cabi.profile_read()
+    _cabi.profile_enable(False)
+    k = {n: v[0] / v[1] * 1e3 for n, v in p.items()}
+    calls = {n: v[1] / 5 for n, v in p.items()}
+    per_iter = sum(k[n] * calls[n] for n in k)
+    print(f"{N} Gaussians @ {W}x{H}: mapping, one view in flight, {wall:.0f} us / iteration of 10 views "
+          f"({wall / 10:.1f} us / view), kernels {per_iter:.0f} us / iteration; us per launch (launches per iteration):",
+          {n: (round(v, 1), calls[n]) for n, v in sorted(k.items(), key=lambda kv: -kv[1] * calls[kv[0]])})
+    assert mp.check_capacity() and len(gm) == N
 
 
 if __name__ == "__main__":
