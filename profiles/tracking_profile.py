@@ -44,10 +44,21 @@ def profile(step, warm, timed, prof):
 
 def main():
     dev = torch.device("cuda:0")
-    sizes = [int(a) for a in sys.argv[1:]] or [300000, 8000]
+    spatial = "--tile-order" in sys.argv       # experiment: Gaussians re-ordered by the tile of their projected centre
+    sizes = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [300000, 8000]
     for N in sizes:
         sc = S.make_scene(N, 640, 480, seed=0)
         cam = sc.cam
+        if spatial:
+            p = sc.means3D
+            u = p[:, 0] / p[:, 2] * cam.fx + cam.cx
+            v = p[:, 1] / p[:, 2] * cam.fy + cam.cy
+            key = (v.clamp(0, cam.H - 1) // 16).long() * 64 + (u.clamp(0, cam.W - 1) // 16).long()
+            order = torch.argsort(key, stable=True)
+            sc = sc._replace(means3D=sc.means3D[order].contiguous(), log_scales=sc.log_scales[order].contiguous(),
+                             rot=sc.rot[order].contiguous(), opacity_logit=sc.opacity_logit[order].contiguous(),
+                             features_dc=sc.features_dc[order].contiguous())
+            print("Gaussians in tile order of their projected centres (experiment)")
         H, W = cam.H, cam.W
         gauss = GaussianParams(sc.means3D.to(dev), sc.log_scales.to(dev), sc.rot.to(dev), sc.opacity_logit.to(dev),
                                sc.features_dc.to(dev))
