@@ -95,7 +95,7 @@ int launch_knn(const float* pts, int n, float* out, void* scratch, hipStream_t s
   float* part = (float*)scratch;
   launch("knn_partial", k_knn_partial, dim3(qb, slices), dim3(kKnnBlock), st, pts, n, slice_len, part);
   launch("knn_merge", k_knn_merge, dim3(qb), dim3(kKnnBlock), st, (const float*)part, n, slices, out);
-  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+  return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
 }  // namespace mgs

@@ -365,7 +365,7 @@ int32_t mgs_adam_step_multi(const mgs_adam_group* groups, int32_t num_groups, do
   const long long want = (chunks + 255) / 256;
   const int grid = (int)(want < 1 ? 1 : (want > 65535 * 16 ? 65535 * 16 : want));
   launch("adam_multi", k_adam_multi, dim3(grid), dim3(256), (hipStream_t)stream, A, chunks, vec);
-  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+  return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
 int32_t mgs_pack_mapping_grads(const float* const* grads, const int64_t* numels, int32_t num_grads,
@@ -388,7 +388,7 @@ int32_t mgs_pack_mapping_grads(const float* const* grads, const int64_t* numels,
   long long want = (total + 255) / 256;
   if (want > 8192) want = 8192;
   launch("pack_grads", k_pack_grads, dim3((unsigned)want), dim3(256), (hipStream_t)stream, A);
-  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+  return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
 int32_t mgs_map_plan_blocks(int32_t n) { return n < 1 ? 0 : (n + kPlanBlock - 1) / kPlanBlock; }
@@ -404,13 +404,13 @@ int32_t mgs_map_plan_count(const mgs_map_plan_args* a, void* stream) {
   const int nb = mgs_map_plan_blocks(a->n);
   launch("plan_count", k_plan_count, dim3(nb), dim3(kPlanBlock), (hipStream_t)stream, *a);
   launch("plan_scan", k_plan_scan, dim3(1), dim3(1024), (hipStream_t)stream, *a, nb);
-  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+  return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
 int32_t mgs_map_plan_emit(const mgs_map_plan_args* a, void* stream) {
   if (!plan_ok(a) || !a->src_index || !a->noise_row) return MGS_ERR_BAD_ARGUMENT;
   launch("plan_emit", k_plan_emit, dim3(mgs_map_plan_blocks(a->n)), dim3(kPlanBlock), (hipStream_t)stream, *a);
-  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+  return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
 int32_t mgs_map_gather(const mgs_map_gather_args* a, void* stream) {
@@ -433,7 +433,7 @@ int32_t mgs_map_gather(const mgs_map_gather_args* a, void* stream) {
   long long want = (a->rows * maxw + 255) / 256;
   if (want > 4096) want = 4096;
   launch("gather_rows", k_gather_rows, dim3((unsigned)want, (unsigned)a->num_tensors), dim3(256), (hipStream_t)stream, G);
-  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+  return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
 int32_t mgs_map_activate(const mgs_map_activate_args* a, void* stream) {
@@ -443,7 +443,7 @@ int32_t mgs_map_activate(const mgs_map_activate_args* a, void* stream) {
   if (a->shs && (!a->features_dc || (a->sh_coeffs > 1 && !a->features_rest))) return MGS_ERR_BAD_ARGUMENT;
   if (!a->shs && a->sh_coeffs != 1) return MGS_ERR_BAD_ARGUMENT;
   launch("map_activate", k_map_activate, dim3((a->num_gaussians + 255) / 256), dim3(256), (hipStream_t)stream, *a);
-  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+  return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
 int32_t mgs_map_finish_iteration(const mgs_map_finish_args* a, void* stream) {
@@ -456,7 +456,7 @@ int32_t mgs_map_finish_iteration(const mgs_map_finish_args* a, void* stream) {
   // inverse_sigmoid(x) = log(x / (1 - x))   (gaussian_splatting/utils/general_utils.py)
   const float logit = a->reset_mode ? (float)log((double)a->reset_value / (1.0 - (double)a->reset_value)) : 0.f;
   launch("map_finish", k_map_finish, dim3((a->num_gaussians + 255) / 256), dim3(256), (hipStream_t)stream, *a, logit);
-  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+  return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
 int32_t mgs_map_append(const mgs_map_append_args* a, void* stream) {
@@ -476,7 +476,7 @@ int32_t mgs_map_append(const mgs_map_append_args* a, void* stream) {
   long long want = ((a->rows_old + a->rows_new) * maxw + 255) / 256;
   if (want > 4096) want = 4096;
   launch("map_append", k_map_append, dim3((unsigned)want, (unsigned)a->num_tensors), dim3(256), (hipStream_t)stream, G);
-  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+  return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
 }  // extern "C"

@@ -818,7 +818,7 @@ __global__ __launch_bounds__(768) void k_tau_reduce(KB B, int nblk) {
 
 int launch_visibility(const int* n_touched, unsigned char* vis, int n, hipStream_t st) {
   launch("visibility", k_visibility_only, dim3((n + 255) / 256), dim3(256), st, n_touched, vis, n);
-  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+  return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
 // ---------------------------------------------------------------------------------
@@ -836,7 +836,7 @@ int launch_backward(const KP& P, const KB& B, hipStream_t st, bool skip_tau_redu
     else
       launch("blend_bwd_sketch", k_blend_bwd<true, false>, dim3(grid_pad((P.max_segs + kSketchReps - 1) / kSketchReps, kBwdChunk)), dim3(64), st, P, B);
     launch_smem("sketch_bucket", k_sketch_bucket, dim3(kBucketBlocks), dim3(256), nacc * sizeof(float), st, P, B);
-    if (B.sketch_only) return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+    if (B.sketch_only) return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
   } else {
     if (B.g_means3D || B.map.on)
       launch("blend_bwd", k_blend_bwd<false>, dim3(grid_pad(P.max_segs, kBwdChunk)), dim3(64), st, P, B);
@@ -849,7 +849,7 @@ int launch_backward(const KP& P, const KB& B, hipStream_t st, bool skip_tau_redu
   else if (!P.shs || P.deg == 0) launch("preprocess_bwd", k_preprocess_bwd<false, true>, dim3(npre), dim3(kPreBlock), st, P, B);
   else launch("preprocess_bwd", k_preprocess_bwd<false, false>, dim3(npre), dim3(kPreBlock), st, P, B);
   if (!skip_tau_reduce) launch("tau_reduce", k_tau_reduce, dim3(1), dim3(768), st, B, npre);
-  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+  return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
 }  // namespace mgs

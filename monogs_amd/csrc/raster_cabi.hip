@@ -15,6 +15,10 @@ std::vector<ProfRec> g_prof;
 std::mutex g_prof_mu;
 }  // namespace
 bool profile_on() { return g_prof_on; }
+hipError_t& launch_error_slot() {
+  static thread_local hipError_t e = hipSuccess;
+  return e;
+}
 void profile_push(const char* name, hipEvent_t a, hipEvent_t b) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof.push_back({name, a, b});
@@ -133,7 +137,7 @@ const char* mgs_status_string(int32_t status) {
   switch (status) {
     case MGS_OK: return "ok";
     case MGS_ERR_BAD_ARGUMENT: return "bad argument (null pointer, non-positive size or unsupported degree)";
-    case MGS_ERR_LAUNCH: return "kernel launch failed (hipGetLastError != hipSuccess)";
+    case MGS_ERR_LAUNCH: return "kernel launch failed (the kernel and HIP's message were written to stderr)";
     case MGS_ERR_UNSUPPORTED: return "unsupported configuration";
     default: return "unknown status";
   }

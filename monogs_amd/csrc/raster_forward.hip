@@ -1052,7 +1052,7 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
 
 // ---------------------------------------------------------------------------------
 static inline int check_launch() {
-  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+  return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
 static inline int num_cus() {

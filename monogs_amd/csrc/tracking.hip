@@ -841,7 +841,7 @@ int32_t mgs_camera_from_pose(const float* T, const float* projection, float* vie
   if (!T || !projection || !viewmatrix || !projmatrix) return MGS_ERR_BAD_ARGUMENT;
   launch("camera_from_pose", k_camera_from_pose, dim3(1), dim3(64), (hipStream_t)stream, T, projection,
          viewmatrix, projmatrix);
-  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+  return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
 int32_t mgs_pose_adam_step(const mgs_pose_adam_args* a, void* stream) {
@@ -851,7 +851,7 @@ int32_t mgs_pose_adam_step(const mgs_pose_adam_args* a, void* stream) {
     return MGS_ERR_BAD_ARGUMENT;
   if ((a->grad_a && !a->exposure_a) || (a->grad_b && !a->exposure_b)) return MGS_ERR_BAD_ARGUMENT;
   launch("pose_adam_update", k_pose_adam_update, dim3(1), dim3(512), (hipStream_t)stream, *a);
-  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+  return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
 static bool map_args_ok(const mgs_mapping_loss_args* a) {
@@ -867,7 +867,7 @@ int32_t mgs_mapping_loss_forward(const mgs_mapping_loss_args* a, void* stream) {
   launch("map_loss_fwd", k_map_loss_fwd, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a, a->partial_ticket_ready ? 1 : 0);
   if (!a->partial_ticket_ready)
     launch("map_loss_finish", k_map_loss_finish, dim3(1), dim3(kLossBlock), (hipStream_t)stream, *a, nb);
-  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+  return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
 int32_t mgs_mapping_loss_backward(const mgs_mapping_loss_args* a, void* stream) {
@@ -876,7 +876,7 @@ int32_t mgs_mapping_loss_backward(const mgs_mapping_loss_args* a, void* stream) 
   launch("map_loss_bwd", k_map_loss_bwd, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a);
   if (a->grad_a || a->grad_b)   // exposure gradients are the only consumers of the partial sums
     launch("map_loss_bwd_fin", k_map_loss_bwd_finish, dim3(1), dim3(kLossBlock), (hipStream_t)stream, *a, nb);
-  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+  return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
 int32_t mgs_mapping_loss_partial_count(int64_t num_pixels) { return 4 * loss_blocks(num_pixels) + 1; }
@@ -897,7 +897,7 @@ int32_t mgs_mapping_loss_fused(const mgs_mapping_loss_args* a, int32_t* nblk_out
     launch("map_loss_fused", k_map_loss_fused<false>, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a);
   }
   if (nblk_out) *nblk_out = nb;
-  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+  return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
 int32_t mgs_lm_solve_step(const mgs_lm_step_args* a, void* stream) {
@@ -906,7 +906,7 @@ int32_t mgs_lm_solve_step(const mgs_lm_step_args* a, void* stream) {
   if (a->lm_state ? (!a->loss || !(a->increase_factor > 0.f) || !(a->decrease_factor > 0.f)) : !(a->lambda > 0.f))
     return MGS_ERR_BAD_ARGUMENT;
   launch("lm_solve_step", k_lm_solve_step, dim3(1), dim3(256), (hipStream_t)stream, *a);
-  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+  return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
 int32_t mgs_sketch_assign(int64_t num_pixels, int32_t stack_dim, int32_t sketch_dim, uint64_t key,
@@ -927,7 +927,7 @@ int32_t mgs_sketch_assign(int64_t num_pixels, int32_t stack_dim, int32_t sketch_
   const int nb = loss_blocks(num_pixels);
   launch("sketch_assign", k_sketch_assign, dim3(nb), dim3(256), (hipStream_t)stream, (long long)num_pixels, chunk,
          d, bits, k0, k1, k2, bucket, weights);
-  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+  return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
 int32_t mgs_sketch_residual(const mgs_sketch_residual_args* a, void* stream) {
@@ -940,7 +940,7 @@ int32_t mgs_sketch_residual(const mgs_sketch_residual_args* a, void* stream) {
   const int64_t want = (a->num_pixels + kLossBlock - 1) / kLossBlock;
   const int nb = (int)(want < kSketchBlocks ? want : kSketchBlocks);
   launch_smem("sketch_residual", k_sketch_residual, dim3(nb), dim3(kLossBlock), smem, (hipStream_t)stream, *a);
-  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+  return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
 int32_t mgs_tracking_loss_partial_count(int64_t num_pixels) { return 4 * loss_blocks(num_pixels); }
@@ -955,7 +955,7 @@ int32_t mgs_tracking_loss_fused(const mgs_tracking_loss_args* a, int32_t* nblk_o
   launch("track_loss_fwd", k_track_loss_fwd, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a);
   launch("track_loss_bwd", k_track_loss_bwd, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a, nb);
   if (nblk_out) *nblk_out = nb;
-  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+  return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
 int32_t mgs_tracking_loss_onepass(const mgs_tracking_loss_args* a, int32_t* nblk_out, void* stream) {
@@ -973,7 +973,7 @@ int32_t mgs_tracking_loss_onepass(const mgs_tracking_loss_args* a, int32_t* nblk
     launch("track_loss", k_track_loss_onepass<false>, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a);
   }
   if (nblk_out) *nblk_out = nb;
-  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+  return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
 int32_t mgs_tracking_loss_forward(const mgs_tracking_loss_args* a, void* stream) {
@@ -983,7 +983,7 @@ int32_t mgs_tracking_loss_forward(const mgs_tracking_loss_args* a, void* stream)
   const int nb = loss_blocks(a->num_pixels);
   launch("track_loss_fwd", k_track_loss_fwd, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a);
   launch("track_loss_finish", k_track_loss_finish, dim3(1), dim3(kLossBlock), (hipStream_t)stream, *a, nb);
-  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+  return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
 int32_t mgs_tracking_loss_backward(const mgs_tracking_loss_args* a, void* stream) {
@@ -993,7 +993,7 @@ int32_t mgs_tracking_loss_backward(const mgs_tracking_loss_args* a, void* stream
   const int nb = loss_blocks(a->num_pixels);
   launch("track_loss_bwd", k_track_loss_bwd, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a, 0);
   launch("track_loss_bwd_fin", k_track_loss_bwd_finish, dim3(1), dim3(kLossBlock), (hipStream_t)stream, *a, nb);
-  return hipGetLastError() == hipSuccess ? MGS_OK : MGS_ERR_LAUNCH;
+  return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
 }  // extern "C"
