@@ -202,6 +202,12 @@ def lib():
         raise NativeLibraryError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback.")
+    # PyTorch first: its wheel carries its own copy of the HIP runtime.  If this library were loaded before
+    # torch, its DT_NEEDED libamdhip64 would bind to the system copy, torch would bring in (and initialise)
+    # a second runtime instance, and launches through this library fail with "no ROCm-capable device is
+    # detected" (seen with `python __graft_entry__.py smoke`, which builds - and used to load - before
+    # importing torch).  With torch's runtime already in the process the loader resolves ours to it.
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     for name in EXPORTS:
         if not hasattr(L, name):
