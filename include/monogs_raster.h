@@ -365,6 +365,12 @@ typedef struct mgs_lm_step_args {
    * criterion, the pose / exposure this iteration rendered (before the step) is what is stored. */
   int32_t reserved0;
   float* best;
+  /* optional (all three or none): the camera matrices of the STEPPED pose are written here (viewmatrix = T^T,
+   * projmatrix = viewmatrix @ projection) - mgs_tracking_iteration_second_order then needs no
+   * mgs_camera_from_pose launch in the next iteration (base.camera_matrices_valid) */
+  const float* projection;
+  float* viewmatrix_out;
+  float* projmatrix_out;
 } mgs_lm_step_args;
 
 int32_t mgs_lm_solve_step(const mgs_lm_step_args* args, void* stream);
@@ -488,13 +494,19 @@ typedef struct mgs_sketch_residual_args {
   float* Sf;                 /* [stack*sketch] accumulated */
   float* sj_exposure;        /* [stack*sketch, 2] accumulated */
   float* l1;                 /* [1] accumulated */
+  /* assign != 0: the partition of mgs_sketch_assign(num_pixels, stack_dim, sketch_dim, assign_key) is
+   * evaluated inside this pass and WRITTEN to bucket / weights (which then are outputs): one launch less */
+  int32_t assign;
+  int32_t reserved0;
+  uint64_t assign_key;
 } mgs_sketch_residual_args;
 
 int32_t mgs_sketch_residual(const mgs_sketch_residual_args* args, void* stream);
 
 /* One second-order iteration as a fixed launch sequence (no host round trip): camera
- * matrices from T -> forward -> zero accumulators -> mgs_sketch_assign(key) ->
- * mgs_sketch_residual -> Jacobian-only backward in sketch mode (grad_sketch_dtau via the compact
+ * matrices from T (skipped when base.camera_matrices_valid: the previous iteration's LM kernel wrote them) ->
+ * forward -> zero accumulators -> mgs_sketch_residual with the partition of mgs_sketch_assign(key)
+ * evaluated inside it -> Jacobian-only backward in sketch mode (grad_sketch_dtau via the compact
  * bucket map; the per-splat sums, the per-Gaussian chain and grad_tau are skipped: the LM step
  * consumes the sketched Jacobian alone) -> mgs_lm_solve_step with the device-resident
  * trust-region state.

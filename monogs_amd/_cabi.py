@@ -105,7 +105,8 @@ class LMStepArgs(C.Structure):
                 ("sj_tau", _fp), ("sj_exposure", _fp), ("lm_state", _fp), ("loss", _fp),
                 ("increase_factor", C.c_float), ("decrease_factor", C.c_float),
                 ("min_lambda", C.c_float), ("max_lambda", C.c_float), ("converged_threshold", C.c_float),
-                ("reserved0", C.c_int32), ("best", _fp)]
+                ("reserved0", C.c_int32), ("best", _fp), ("projection", _fp), ("viewmatrix_out", _fp),
+                ("projmatrix_out", _fp)]
 
 
 class TrackingLossArgs(C.Structure):
@@ -125,7 +126,8 @@ class SketchResidualArgs(C.Structure):
     _fields_ = ([(n, _fp) for n in ("image", "opacity", "gt", "mask", "exposure_a", "exposure_b")]
                 + [("exposure_eps", C.c_float), ("huber_delta", C.c_float), ("num_pixels", C.c_int64),
                    ("stack_dim", C.c_int32), ("sketch_dim", C.c_int32)]
-                + [(n, _fp) for n in ("bucket", "weights", "grad_image", "Sf", "sj_exposure", "l1")])
+                + [(n, _fp) for n in ("bucket", "weights", "grad_image", "Sf", "sj_exposure", "l1")]
+                + [("assign", C.c_int32), ("reserved0", C.c_int32), ("assign_key", C.c_uint64)])
 
 
 class TrackingSOArgs(C.Structure):

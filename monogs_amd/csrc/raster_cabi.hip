@@ -355,18 +355,18 @@ int32_t mgs_tracking_iteration_second_order(const mgs_tracking_so_args* args, vo
   float* sj_exp = Sf + d;
   float* sj_tau = sj_exp + 2 * (size_t)d;
   float* l1 = sj_tau + 6 * (size_t)d;
-  int32_t rc = mgs_camera_from_pose(b.adam.T, b.fwd.projmatrix_raw, const_cast<float*>(b.fwd.viewmatrix),
-                                    const_cast<float*>(b.fwd.projmatrix), stream);
-  if (rc != MGS_OK) return rc;
+  int32_t rc = MGS_OK;
+  if (!b.camera_matrices_valid) {
+    rc = mgs_camera_from_pose(b.adam.T, b.fwd.projmatrix_raw, const_cast<float*>(b.fwd.viewmatrix),
+                              const_cast<float*>(b.fwd.projmatrix), stream);
+    if (rc != MGS_OK) return rc;
+  }
   if ((rc = mgs_raster_forward_project(&b.fwd, stream)) != MGS_OK) return rc;
   if ((rc = mgs_raster_forward_blend(&b.fwd, stream)) != MGS_OK) return rc;
   // Sf, sj_exposure and l1 are accumulated with atomics (sj_tau is zeroed by the backward)
   if (hipMemsetAsync(Sf, 0, sizeof(float) * 3 * (size_t)d, (hipStream_t)stream) != hipSuccess ||
       hipMemsetAsync(l1, 0, sizeof(float) * 4, (hipStream_t)stream) != hipSuccess)
     return MGS_ERR_LAUNCH;
-  if ((rc = mgs_sketch_assign(HW, args->stack_dim, args->sketch_dim, args->key, args->bucket, args->weights,
-                              stream)) != MGS_OK)
-    return rc;
   mgs_sketch_residual_args R;
   memset(&R, 0, sizeof(R));
   R.image = b.fwd.out_color; R.opacity = b.fwd.out_opacity; R.gt = b.loss.gt; R.mask = b.loss.mask;
@@ -375,6 +375,7 @@ int32_t mgs_tracking_iteration_second_order(const mgs_tracking_so_args* args, vo
   R.stack_dim = args->stack_dim; R.sketch_dim = args->sketch_dim;
   R.bucket = args->bucket; R.weights = args->weights; R.grad_image = b.grad_image;
   R.Sf = Sf; R.sj_exposure = sj_exp; R.l1 = l1;
+  R.assign = 1; R.assign_key = args->key;     // the bucket partition is drawn inside the residual pass
   if ((rc = mgs_sketch_residual(&R, stream)) != MGS_OK) return rc;
   mgs_backward_args B;
   memset(&B, 0, sizeof(B));
@@ -388,6 +389,9 @@ int32_t mgs_tracking_iteration_second_order(const mgs_tracking_so_args* args, vo
   L.SJ = nullptr; L.sj_tau = sj_tau; L.sj_exposure = sj_exp; L.Sf = Sf; L.rows = d; L.loss = l1;
   L.T = b.adam.T; L.exposure_a = b.adam.exposure_a; L.exposure_b = b.adam.exposure_b;
   L.best = b.best;
+  L.projection = b.fwd.projmatrix_raw;
+  L.viewmatrix_out = const_cast<float*>(b.fwd.viewmatrix);
+  L.projmatrix_out = const_cast<float*>(b.fwd.projmatrix);
   return mgs_lm_solve_step(&L, stream);
 }
 

@@ -493,6 +493,20 @@ __global__ __launch_bounds__(256) void k_lm_solve_step(mgs_lm_step_args A) {
         Tn[4 * i + j] = R[3 * i] * A.T[j] + R[3 * i + 1] * A.T[4 + j] + R[3 * i + 2] * A.T[8 + j] +
                         (j == 3 ? t[i] : 0.f) * A.T[15];
     for (int i = 0; i < 12; i++) A.T[i] = Tn[i];
+    if (A.projection && A.viewmatrix_out && A.projmatrix_out) {
+      // camera matrices of the stepped pose (viewmatrix = T^T, projmatrix = viewmatrix @ projection), so
+      // that the next iteration needs no mgs_camera_from_pose launch
+      float Tm[16];
+      for (int i = 0; i < 12; i++) Tm[i] = Tn[i];
+      for (int i = 12; i < 16; i++) Tm[i] = A.T[i];
+      for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+          float acc = 0.f;
+          for (int k = 0; k < 4; k++) acc += Tm[4 * k + i] * A.projection[4 * k + j];
+          A.projmatrix_out[4 * i + j] = acc;
+          A.viewmatrix_out[4 * i + j] = Tm[4 * j + i];
+        }
+    }
   }
   if (A.exposure_a) A.exposure_a[0] += (float)x[6];
   if (A.exposure_b) A.exposure_b[0] += (float)x[7];
@@ -779,7 +793,9 @@ __global__ __launch_bounds__(256) void k_sketch_assign(long long m, int chunk, i
 
 constexpr int kSketchBlocks = 256;   // one workgroup per CU (12 KB of LDS bucket sums each)
 
-__global__ __launch_bounds__(kLossBlock) void k_sketch_residual(mgs_sketch_residual_args A) {
+struct SketchKeys { int on, chunk, bits; unsigned int k0, k1, k2; };   // on != 0: assign bucket / weight here
+
+__global__ __launch_bounds__(kLossBlock) void k_sketch_residual(mgs_sketch_residual_args A, SketchKeys K) {
   extern __shared__ float s_acc[];   // [d][3]: Sf, d/da, d/db
   __shared__ float s_red[kLossBlock / 64];
   const int d = A.stack_dim * A.sketch_dim;
@@ -793,7 +809,21 @@ __global__ __launch_bounds__(kLossBlock) void k_sketch_residual(mgs_sketch_resid
   float l1 = 0.f;
   for (size_t p = (size_t)blockIdx.x * kLossBlock + threadIdx.x; p < HW; p += (size_t)gridDim.x * kLossBlock) {
     const float om = A.opacity[p] * (A.mask ? A.mask[p] : 1.f);
-    const float w = A.weights[p] * scale;
+    int b;
+    float wsign;
+    if (K.on) {    // the partition of mgs_sketch_assign, evaluated (and left behind for the backward) in this pass
+      const unsigned int pmask = K.bits >= 32 ? 0xFFFFFFFFu : ((1u << K.bits) - 1u);
+      unsigned int x = (unsigned int)p;
+      do { x = perm_round(x, pmask, K.bits, K.k0, K.k1); } while ((size_t)x >= HW);
+      b = (long long)x < (long long)K.chunk * d ? (int)(x / (unsigned int)K.chunk) : -1;
+      wsign = (hash32((unsigned int)p ^ K.k2) & 0x10000u) ? 1.f : -1.f;
+      const_cast<int32_t*>(A.bucket)[p] = b;
+      const_cast<float*>(A.weights)[p] = wsign;
+    } else {
+      b = A.bucket[p];
+      wsign = A.weights[p];
+    }
+    const float w = wsign * scale;
     float hs = 0.f, da = 0.f, db = 0.f;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
@@ -807,7 +837,6 @@ __global__ __launch_bounds__(kLossBlock) void k_sketch_residual(mgs_sketch_resid
       da += g * im;
       db += g;
     }
-    const int b = A.bucket[p];
     if (b >= 0 && b < d) {
       atomicAdd(&s_acc[3 * b], w * hs);
       atomicAdd(&s_acc[3 * b + 1], da * sg);
@@ -909,24 +938,30 @@ int32_t mgs_lm_solve_step(const mgs_lm_step_args* a, void* stream) {
   return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
-int32_t mgs_sketch_assign(int64_t num_pixels, int32_t stack_dim, int32_t sketch_dim, uint64_t key,
-                          int32_t* bucket, float* weights, void* stream) {
-  if (num_pixels < 1 || num_pixels > 0x7fffffffLL || stack_dim < 1 || sketch_dim < 1 || !bucket || !weights)
-    return MGS_ERR_BAD_ARGUMENT;
+// chunk size, index bits and the three 32-bit round keys (splitmix64 of the 64-bit key) of the partition
+static bool sketch_keys(int64_t num_pixels, int32_t stack_dim, int32_t sketch_dim, uint64_t key, SketchKeys& K) {
+  if (num_pixels < 1 || num_pixels > 0x7fffffffLL || stack_dim < 1 || sketch_dim < 1) return false;
   const int d = stack_dim * sketch_dim;
-  const int chunk = (int)(num_pixels / d);
-  if (chunk < 1) return MGS_ERR_BAD_ARGUMENT;
-  int bits = 1;
-  while ((1LL << bits) < num_pixels) bits++;
-  // three 32-bit round keys from the 64-bit key (splitmix64)
+  K.chunk = (int)(num_pixels / d);
+  if (K.chunk < 1) return false;
+  K.bits = 1;
+  while ((1LL << K.bits) < num_pixels) K.bits++;
   uint64_t z = key + 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
-  const unsigned int k0 = (unsigned int)z, k1 = (unsigned int)(z >> 32);
+  K.k0 = (unsigned int)z; K.k1 = (unsigned int)(z >> 32);
   z = (z + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull; z ^= z >> 29;
-  const unsigned int k2 = (unsigned int)(z >> 16);
+  K.k2 = (unsigned int)(z >> 16);
+  K.on = 1;
+  return true;
+}
+
+int32_t mgs_sketch_assign(int64_t num_pixels, int32_t stack_dim, int32_t sketch_dim, uint64_t key,
+                          int32_t* bucket, float* weights, void* stream) {
+  SketchKeys K;
+  if (!bucket || !weights || !sketch_keys(num_pixels, stack_dim, sketch_dim, key, K)) return MGS_ERR_BAD_ARGUMENT;
   const int nb = loss_blocks(num_pixels);
-  launch("sketch_assign", k_sketch_assign, dim3(nb), dim3(256), (hipStream_t)stream, (long long)num_pixels, chunk,
-         d, bits, k0, k1, k2, bucket, weights);
+  launch("sketch_assign", k_sketch_assign, dim3(nb), dim3(256), (hipStream_t)stream, (long long)num_pixels, K.chunk,
+         stack_dim * sketch_dim, K.bits, K.k0, K.k1, K.k2, bucket, weights);
   return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
@@ -939,7 +974,9 @@ int32_t mgs_sketch_residual(const mgs_sketch_residual_args* a, void* stream) {
   if (smem > 48 * 1024) return MGS_ERR_UNSUPPORTED;
   const int64_t want = (a->num_pixels + kLossBlock - 1) / kLossBlock;
   const int nb = (int)(want < kSketchBlocks ? want : kSketchBlocks);
-  launch_smem("sketch_residual", k_sketch_residual, dim3(nb), dim3(kLossBlock), smem, (hipStream_t)stream, *a);
+  SketchKeys K = {0, 0, 0, 0u, 0u, 0u};
+  if (a->assign && !sketch_keys(a->num_pixels, a->stack_dim, a->sketch_dim, a->assign_key, K)) return MGS_ERR_BAD_ARGUMENT;
+  launch_smem("sketch_residual", k_sketch_residual, dim3(nb), dim3(kLossBlock), smem, (hipStream_t)stream, *a, K);
   return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 

@@ -177,11 +177,12 @@ class NativeTracker:
         so.base.fwd.shape.pair_capacity = self.args.fwd.shape.pair_capacity
         so.base.adam.T = self.args.adam.T
         so.base.best = self.args.best
+        so.base.camera_matrices_valid = 1 if self._matrices_fresh else 0
         self.so_t += 1
         so.key = (self.so_seed * 0x9E3779B97F4A7C15 + self.so_t) & 0xFFFFFFFFFFFFFFFF
         _cabi.check(_cabi.lib().mgs_tracking_iteration_second_order(C.byref(so), self._stream()),
                     "mgs_tracking_iteration_second_order")
-        self._matrices_fresh = False     # the LM step moved T
+        self._matrices_fresh = True      # the LM kernel wrote the matrices of the stepped pose
         return self.lm_state
 
     @property
