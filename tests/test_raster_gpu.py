@@ -693,14 +693,17 @@ def test_fused_tracking_iteration_converges_like_the_reference_loop(built):
     assert torch.allclose(va.T, vb.T, atol=1e-4)
 
 
-def test_native_tracking_matches_python_loop(built):
+@pytest.mark.parametrize("W,H", [(160, 120), (150, 101)])
+def test_native_tracking_matches_python_loop(built, W, H):
     """mgs_tracking_iteration (one C-ABI call per iteration, pose-only backward) follows the
-    same pose / exposure / loss trajectory as the reference-shaped Python loop body."""
+    same pose / exposure / loss trajectory as the reference-shaped Python loop body.  (150x101: the
+    pixel count is not a multiple of 4 - the scalar form of the one-pass tracking objective - and the
+    image is not a whole number of tiles.)"""
     from monogs_amd.gaussian_renderer import render
     from monogs_amd.pose import SE3_exp
     from monogs_amd.slam_loops import Pipe, make_pose_optimizer, tracking_step_first_order
     from monogs_amd.tracking_native import NativeTracker
-    sc, gauss, view, dev = _loop_fixture()
+    sc, gauss, view, dev = _loop_fixture(W=W, H=H)
     bg = torch.zeros(3, device=dev)
     with torch.no_grad():
         target = render(view(1, torch.eye(4)), gauss, Pipe, bg)["render"].clone()
@@ -1265,13 +1268,14 @@ def test_tile_scan_handoff_never_reads_stale_counts(built):
     assert abs(int(toff[T]) - em.pairs) <= max(2, em.pairs // 1000)
 
 
-def test_fused_loss_backward_helper_matches_autograd(built):
+@pytest.mark.parametrize("H,W", [(75, 133), (76, 132)])
+def test_fused_loss_backward_helper_matches_autograd(built, H, W):
     """l1_image_depth_loss_backward: value + gradients in one launch, handed to autograd - equal to
-    loss.backward() of the torch formulation incl. the exposure path and the masks."""
+    loss.backward() of the torch formulation incl. the exposure path and the masks.  75x133 pixels are
+    not a multiple of 4 (scalar form of k_map_loss_fused), 76x132 are (four pixels per thread)."""
     from monogs_amd.tracking_fused import l1_image_depth_loss_backward
     dev = _dev()
     g = torch.Generator().manual_seed(5)
-    H, W = 75, 133
 
     class VP:
         pass
