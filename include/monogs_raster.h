@@ -371,6 +371,11 @@ typedef struct mgs_lm_step_args {
   const float* projection;
   float* viewmatrix_out;
   float* projmatrix_out;
+  /* optional: zero_count floats at zero_after are set to 0 once every row has been read (the sketch
+   * accumulators of the native second-order iteration: their consumer leaves them ready for the next one) */
+  float* zero_after;
+  int32_t zero_count;
+  int32_t reserved1;
 } mgs_lm_step_args;
 
 int32_t mgs_lm_solve_step(const mgs_lm_step_args* args, void* stream);
@@ -521,6 +526,11 @@ typedef struct mgs_tracking_so_args {
   float* accum;
   void* sketch_ws;           /* sketch_bytes of backward scratch */
   mgs_lm_step_args lm;       /* SJ / Sf / sj_* / loss fields are filled in by the call */
+  /* != 0: `accum` and `sketch_ws` were zero-filled before the FIRST call and nobody else writes them; the
+   * iteration's own kernels restore the zeros they need (the LM kernel: accum; the bucket kernel: the
+   * per-pixel Jacobian rows), so no hipMemsetAsync is enqueued per iteration */
+  int32_t scratch_kept_zero;
+  int32_t reserved0;
 } mgs_tracking_so_args;
 
 int32_t mgs_tracking_iteration_second_order(const mgs_tracking_so_args* args, void* stream);

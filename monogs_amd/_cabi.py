@@ -106,7 +106,7 @@ class LMStepArgs(C.Structure):
                 ("increase_factor", C.c_float), ("decrease_factor", C.c_float),
                 ("min_lambda", C.c_float), ("max_lambda", C.c_float), ("converged_threshold", C.c_float),
                 ("reserved0", C.c_int32), ("best", _fp), ("projection", _fp), ("viewmatrix_out", _fp),
-                ("projmatrix_out", _fp)]
+                ("projmatrix_out", _fp), ("zero_after", _fp), ("zero_count", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class TrackingLossArgs(C.Structure):
@@ -133,7 +133,7 @@ class SketchResidualArgs(C.Structure):
 class TrackingSOArgs(C.Structure):
     _fields_ = [("base", TrackingIterArgs), ("stack_dim", C.c_int32), ("sketch_dim", C.c_int32),
                 ("key", C.c_uint64), ("bucket", _fp), ("weights", _fp), ("accum", _fp),
-                ("sketch_ws", _fp), ("lm", LMStepArgs)]
+                ("sketch_ws", _fp), ("lm", LMStepArgs), ("scratch_kept_zero", C.c_int32), ("reserved0", C.c_int32)]
 
 
 ADAM_MAX_GROUPS = 8

@@ -525,6 +525,10 @@ __global__ __launch_bounds__(256) void k_sketch_bucket(KP P, KB B) {
     float J[6];
 #pragma unroll
     for (int t = 0; t < 6; t++) J[t] = B.pix_jac[(size_t)t * HW + p];
+    if (B.scratch_kept_zero) {   // this kernel is the rows' only consumer: leave them zero for the next backward
+#pragma unroll
+      for (int t = 0; t < 6; t++) B.pix_jac[(size_t)t * HW + p] = 0.f;
+    }
     if (B.sketch_flat) {      // one bucket per pixel
       const int b = B.sketch_flat[p];
       if (b >= 0 && b < B.stack_dim * B.sketch_dim) {
@@ -827,8 +831,9 @@ int launch_backward(const KP& P, const KB& B, hipStream_t st, bool skip_tau_redu
     const size_t HW = (size_t)P.W * P.H;
     const size_t nacc = (size_t)B.stack_dim * B.sketch_dim * 6;
     if (nacc * sizeof(float) > 64 * 1024) return MGS_ERR_UNSUPPORTED;
-    if (hipMemsetAsync(B.pix_jac, 0, HW * 6 * sizeof(float), st) != hipSuccess ||
-        hipMemsetAsync(B.g_sketch, 0, nacc * sizeof(float), st) != hipSuccess)
+    if (!B.scratch_kept_zero &&
+        (hipMemsetAsync(B.pix_jac, 0, HW * 6 * sizeof(float), st) != hipSuccess ||
+         hipMemsetAsync(B.g_sketch, 0, nacc * sizeof(float), st) != hipSuccess))
       return MGS_ERR_LAUNCH;
     launch("sketch_prep", k_sketch_prep, dim3((P.N + kPreBlock - 1) / kPreBlock), dim3(kPreBlock), st, P, B);
     if (B.sketch_only)

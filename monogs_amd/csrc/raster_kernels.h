@@ -72,6 +72,8 @@ struct KB {   // backward extras
   float *g_means3D, *g_means2D, *g_colors, *g_opac, *g_scales, *g_rots, *g_cov, *g_tau;
   int sketch_mode, sketch_dim, stack_dim;
   int sketch_only;          // sketch mode: produce grad_sketch_dtau only (no per-splat sums, no grad_tau)
+  int scratch_kept_zero;    // sketch mode: pix_jac and g_sketch are zero on entry and their consumers restore the
+                            // zeros (native second-order iteration: no hipMemsetAsync launches per iteration)
   const int* sketch_idx;
   const int* sketch_flat;   // [H*W] stack * sketch_dim + bucket or -1 (compact alternative)
   float* g_sketch;

@@ -388,6 +388,7 @@ __global__ __launch_bounds__(kLossBlock) void k_track_loss_onepass(mgs_tracking_
 // host-side solver setup per call.)
 __global__ __launch_bounds__(256) void k_lm_solve_step(mgs_lm_step_args A) {
   __shared__ double s_red[4][44];
+  const float loss_in = A.loss ? A.loss[0] : 0.f;     // read before the accumulators are zeroed below
   double acc[44];
 #pragma unroll
   for (int i = 0; i < 44; i++) acc[i] = 0.0;
@@ -418,6 +419,9 @@ __global__ __launch_bounds__(256) void k_lm_solve_step(mgs_lm_step_args A) {
     if (lane == 0) s_red[wave][i] = v;
   }
   __syncthreads();
+  // every thread has read its rows: leave the accumulators zero for the next iteration (zero_after)
+  if (A.zero_after)
+    for (int i = threadIdx.x; i < A.zero_count; i += 256) A.zero_after[i] = 0.f;
   if (threadIdx.x != 0) return;
   if (A.lm_state && A.lm_state[3] != 0.f) return;      // converged earlier: the reference has left its loop
   double H[8][8], g[8];
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(256) void k_lm_solve_step(mgs_lm_step_args A) {
   float lambda = A.lambda;
   if (A.lm_state) {      // trust-region rule on the device (slam_frontend.py:536-545)
     lambda = A.lm_state[0];
-    const float loss = A.loss[0];
+    const float loss = loss_in;
     if (A.lm_state[2] != 0.f)
       lambda = loss < A.lm_state[1] ? fmaxf(lambda / A.decrease_factor, A.min_lambda)
                                     : fminf(lambda * A.increase_factor, A.max_lambda);
@@ -470,8 +474,8 @@ __global__ __launch_bounds__(256) void k_lm_solve_step(mgs_lm_step_args A) {
   }
   if (A.best && A.loss && A.T) {     // best iterate = the state this iteration rendered (before the step)
     const float count = A.best[20];
-    if (A.loss[0] < A.best[0]) {
-      A.best[0] = A.loss[0];
+    if (loss_in < A.best[0]) {
+      A.best[0] = loss_in;
       for (int i = 0; i < 16; i++) A.best[1 + i] = A.T[i];
       A.best[17] = A.exposure_a ? A.exposure_a[0] : 0.f;
       A.best[18] = A.exposure_b ? A.exposure_b[0] : 0.f;

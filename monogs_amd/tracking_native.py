@@ -144,8 +144,11 @@ class NativeTracker:
     # ---- second order (sketched Levenberg-Marquardt, slam_frontend.py:455-710) ----------
     def enable_second_order(self, stack_dim=16, sketch_dim=64, initial_lambda=1e-3, max_lambda=1e7,
                             min_lambda=1e-6, increase_factor=5.0, decrease_factor=5.0,
-                            converged_threshold=1e-5, seed=0):
-        """Allocate the sketch scratch; defaults are configs/mono/tum/base_config.yaml:255-268."""
+                            converged_threshold=1e-5, seed=0, keep_sketch=False):
+        """Allocate the sketch scratch; defaults are configs/mono/tum/base_config.yaml:255-268.
+        `keep_sketch`: leave Sf / SJ of the last iteration readable (`self.sketch`) - the accumulators are
+        then cleared by memset launches at the start of an iteration instead of by their consumer at its end
+        (four launches more per iteration)."""
         dev, HW = self.dev, self.H * self.W
         d = stack_dim * sketch_dim
         so = _cabi.TrackingSOArgs()
@@ -154,7 +157,9 @@ class NativeTracker:
         self.so_bucket = torch.empty(HW, dtype=torch.int32, device=dev)
         self.so_weights = torch.empty(HW, device=dev)
         self.so_accum = torch.zeros(9 * d + 4, device=dev)
-        self.so_sketch_ws = torch.empty(int(sizes.sketch_bytes), dtype=torch.uint8, device=dev)
+        # zero-filled once: the iteration's kernels keep the accumulators and the Jacobian rows zero
+        # between calls (scratch_kept_zero), so no memset launches are needed per iteration
+        self.so_sketch_ws = torch.zeros(int(sizes.sketch_bytes), dtype=torch.uint8, device=dev)
         self.lm_state = torch.tensor([initial_lambda, 0.0, 0.0, 0.0], device=dev)
         self.so_x = torch.zeros(8, device=dev)
         so.stack_dim, so.sketch_dim = stack_dim, sketch_dim
@@ -164,6 +169,7 @@ class NativeTracker:
         so.lm.increase_factor, so.lm.decrease_factor = increase_factor, decrease_factor
         so.lm.min_lambda, so.lm.max_lambda = min_lambda, max_lambda
         so.lm.converged_threshold = converged_threshold
+        so.scratch_kept_zero = 0 if keep_sketch else 1
         self.so_args, self.so_d, self.so_seed, self.so_t = so, d, int(seed), 0
 
     def step_second_order(self):
@@ -187,7 +193,10 @@ class NativeTracker:
 
     @property
     def sketch(self):
-        """(Sf [d], SJ [d, 8]) of the last second-order iteration (views / a small cat)."""
+        """(Sf [d], SJ [d, 8]) of the last second-order iteration (views / a small cat); needs
+        enable_second_order(keep_sketch=True) - otherwise the LM kernel has zeroed them again."""
+        if self.so_args.scratch_kept_zero:
+            raise RuntimeError("enable_second_order(keep_sketch=True) is needed to read the sketch back")
         d = self.so_d
         a = self.so_accum
         return a[:d], torch.cat((a[3 * d:9 * d].view(d, 6), a[d:3 * d].view(d, 2)), dim=1)

@@ -1141,7 +1141,17 @@ def test_native_second_order_iteration_matches_python_formulation(built):
     H, W = va.image_height, va.image_width
     stack, sketch, lam = 4, 16, 1e-3
     trk = NativeTracker(vb, gauss, bg)
-    trk.enable_second_order(stack_dim=stack, sketch_dim=sketch, initial_lambda=lam, seed=5)
+    trk.enable_second_order(stack_dim=stack, sketch_dim=sketch, initial_lambda=lam, seed=5, keep_sketch=True)
+    # the default form (accumulators cleared by their consumers, no memset launches) takes the same step
+    vc = view(4, T0)
+    vc.original_image, vc.rgb_pixel_mask_mapping = target, vb.rgb_pixel_mask_mapping
+    with torch.no_grad():
+        vc.exposure_a.fill_(0.97)
+        vc.exposure_b.fill_(0.01)
+    trk_fast = NativeTracker(vc, gauss, bg)
+    trk_fast.enable_second_order(stack_dim=stack, sketch_dim=sketch, initial_lambda=lam, seed=5)
+    for _ in range(3):
+        trk_fast.step_second_order()
     state = trk.step_second_order()
     torch.cuda.synchronize()
     Sf_n, SJ_n = trk.sketch
@@ -1164,6 +1174,20 @@ def test_native_second_order_iteration_matches_python_formulation(built):
     for _ in range(6):
         trk.step_second_order()
     assert trk.check_capacity()
+    # three iterations of the memset-free form = the first three of the other one (same partitions; the
+    # bucket sums are float atomics, so not bit for bit)
+    vd = view(5, T0)
+    vd.original_image, vd.rgb_pixel_mask_mapping = target, vb.rgb_pixel_mask_mapping
+    with torch.no_grad():
+        vd.exposure_a.fill_(0.97)
+        vd.exposure_b.fill_(0.01)
+    trk_ref = NativeTracker(vd, gauss, bg)
+    trk_ref.enable_second_order(stack_dim=stack, sketch_dim=sketch, initial_lambda=lam, seed=5, keep_sketch=True)
+    for _ in range(3):
+        trk_ref.step_second_order()
+    assert torch.allclose(vc.T, vd.T, atol=1e-5) and torch.allclose(vc.exposure_a, vd.exposure_a, atol=1e-5)
+    assert torch.allclose(trk_fast.lm_state, trk_ref.lm_state, rtol=1e-3, atol=1e-6)
+    assert float(trk_fast.so_accum.abs().max()) == 0.0           # left zero for the next iteration
     assert (vb.T.cpu() - torch.eye(4)).abs().max().item() < 0.5 * (T0 - torch.eye(4)).abs().max().item()
 
 
