@@ -204,8 +204,19 @@ __global__ __launch_bounds__(THREADS) void k_bin_lds(KP P, int emit, int per_blo
       }
       if (lane == src) cnt = total;
     }
-    if (!emit) {
-      // block-local exclusive scan of cnt -> slot offset of this Gaussian inside the block
+    if (!emit && idx < g1) {
+      P.pair_count[idx] = cnt;
+      P.hit_mask[idx] = hit;
+    }
+  }
+  if (!emit) {
+    // Block-local exclusive scan of the pair counts -> slot offset of every Gaussian inside the block, in a
+    // second, light walk over the block's Gaussians (each thread re-reads the counts it has just stored).
+    // Inside the main loop the scan's two workgroup barriers made every wave wait for the slowest one of
+    // each trip (9 us of a wave's 29); here the work between the barriers is a load and six shuffles.
+    for (int ibase = g0; ibase < g1; ibase += kBinThreads) {
+      const int idx = ibase + tid;
+      const int cnt = idx < g1 ? P.pair_count[idx] : 0;
       int incl = cnt;
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
@@ -222,15 +233,9 @@ __global__ __launch_bounds__(THREADS) void k_bin_lds(KP P, int emit, int per_blo
         if (w < (tid >> 6)) before += x;
         total += x;
       }
-      if (idx < g1) {
-        P.pair_count[idx] = cnt;
-        P.pair_off[idx] = carry + before + incl - cnt;
-        P.hit_mask[idx] = hit;
-      }
+      if (idx < g1) P.pair_off[idx] = carry + before + incl - cnt;
       carry += total;
     }
-  }
-  if (!emit) {
     __syncthreads();
     for (int t = tid; t < P.T; t += kBinThreads) row[t] = s_tile[t];
     if (tid == 0) {
