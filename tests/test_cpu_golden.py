@@ -182,3 +182,9 @@ def test_full_size_forward_vectors_freeze_the_oracle():
     assert np.array_equal(got["n_touched_thin"], want["n_touched_thin"])
     c = np.load(os.path.join(GOLD, "syn_c_oracle.npz"))
     assert int(c["n_visible"]) > 250000 and c["grad_tau"].shape == (6,) and int(c["g_step"]) == 16
+    # the forward half of syn_c is re-derived as well (about ten seconds); its gradients are not
+    gotc = mod.run(300000, False)
+    assert int(gotc["pairs"]) == int(c["pairs"]) and int(gotc["n_visible"]) == int(c["n_visible"])
+    for k in ("image_sub", "depth_sub", "opacity_sub"):
+        assert np.abs(gotc[k] - c[k]).max() <= 1e-6, k
+    assert np.array_equal(gotc["radii_thin"], c["radii_thin"]) and np.array_equal(gotc["n_touched_thin"], c["n_touched_thin"])
