@@ -563,6 +563,16 @@ def test_more_tiles_than_the_lds_table_falls_back_to_global_atomics(built):
     _against_emulation(sc, m, s, r, o, sh)
 
 
+def test_unpacked_keys_with_the_lds_binning(built):
+    """4096 < T <= 12288 tiles: the LDS-privatised binning with UNPACKED sort keys (the pair index
+    travels in the payload array beside the key: kPackBits only covers T <= 4096) - 1600 x 1088 =
+    100 x 68 = 6800 tiles."""
+    from monogs_amd import synthetic as S
+    sc = S.make_scene(20000, 1600, 1088, seed=36)
+    m, s, r, o, sh = _inputs(sc)
+    _against_emulation(sc, m, s * 3.0, r, o, sh)
+
+
 def test_replica_sized_image_and_background(built):
     """BASELINE config 5 image size (1200 x 680: 75 x 43 tiles, 680 is not a multiple of 16)."""
     from monogs_amd import synthetic as S
