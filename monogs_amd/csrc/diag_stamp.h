@@ -66,7 +66,11 @@ struct BwdStamp {
       g_bstamps[4 * blockIdx.x + 0] = t0;
       g_bstamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
       g_bstamps[4 * blockIdx.x + 2] = ((long long)nany << 32) | nvisit;
+#ifdef MGS_STAMP_PH0   // phase 0 (item start -> per-pixel state in registers) instead of the lane statistics
+      g_bphase[4 * blockIdx.x + 0] = ph[0];
+#else
       g_bphase[4 * blockIdx.x + 0] = ((long long)nmiss << 32) | (unsigned int)nlanes;
+#endif
       g_bstamps[4 * blockIdx.x + 3] = ((long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32) |
                                       __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
       for (int k = 1; k < 3; k++) g_bphase[4 * blockIdx.x + k] = ph[k];

@@ -266,7 +266,10 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
                                   : ((lane & 7) == 0 ? ((lane >> 5) & 1) + 2 * ((lane >> 4) & 1) + 4 * ((lane >> 3) & 1) : -1));
   // byte offset of that dword as an unsigned register (0x80000000...: none): ONE VGPR for offset and
   // predicate - a 64-bit per-lane address and a sign-extended index cost four and spilled at 7 waves / SIMD
-  const unsigned int wofs4 = wofs_ >= 0 ? (unsigned int)wofs_ * 4u : 0x80000000u;
+  const unsigned int wofs4 = wofs_ >= 0 ? (unsigned int)wofs_ * 4u : kPairBufferExtent;
+  // pair_grad as a raw buffer of kPairBufferExtent bytes (the launch refuses a larger one): offsets from
+  // kPairBufferExtent on are out of range (the range check covers soffset + voffset; checked on gfx950)
+  const __amdgpu_buffer_rsrc_t pair_rsrc = __builtin_amdgcn_make_buffer_rsrc(B.pair_grad, 0, kPairBufferExtent, 0x00020000);
   // Packed operands: the per-quadrant body is written on float2 values so that it maps onto
   // v_pk_{add,mul,fma}_f32 without register shuffles (measured on gfx950: a packed FMA issues
   // in about the time of a scalar one, so pairs of independent FMAs halve their issue cost).
@@ -298,14 +301,16 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
       const v2f d = mu - Pq[q];
       // clamped at 0 like the forward's form of the exponent (the quadratic form is <= 0; only
       // rounding can make it positive)
-      const float pw = fminf(0.f, d.x * (u.z * d.x + u.w * d.y) + v.x * d.y * d.y);
-      const float ar = v.y * __builtin_amdgcn_exp2f(pw);
-      const float al = fminf(kAlphaMax, ar);
-      const bool k = (unsigned int)(idx - base) < ((lastp >> (8 * q)) & 0xffu) && al >= kAlphaMin;
+      const float pw = d.x * (u.z * d.x + u.w * d.y) + v.x * d.y * d.y;
+      const float ar = v.y * exp2_sat(pw);
+      const bool k = (unsigned int)(idx - base) < ((lastp >> (8 * q)) & 0xffu) && ar >= kAlphaMin;
       MGS_BLANES(k);
       if (__ballot(k) == 0ull) continue;              // wave-uniform
       any = true;
-      const float ae = k ? al : 0.f;
+      // ak: opacity * G where the splat is blended, else 0; the blended alpha is its clamp at 0.99 and the
+      // gradient flows through the UNclamped product (as upstream: dL/dG = opacity * dL/dalpha)
+      const float ak = k ? ar : 0.f;
+      const float ae = fminf(kAlphaMax, ak);
       const float w = ae * T[q];
       const v2f cc = __builtin_elementwise_fma(G2d[q], BD, G01[q] * RG);
       const float gc = cc.x + cc.y;                   // g . c
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
       const float ro = __builtin_amdgcn_rcpf(om);
       const float dA = T[q] * gc - ro * gS[q];
       T[q] *= om;
-      const float Wt = k ? ar * dA : 0.f;
+      const float Wt = ak * dA;
       const v2f Wxy = v2f{Wt, Wt} * d;                // (W dx, W dy)
       if constexpr (POSE) {
         R12 += Wxy;
@@ -357,10 +362,11 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
         wave_sum10_scatter(r, b3mask, mres, eres);
       }
       const int sj = __builtin_amdgcn_readlane(slot, j);
-      if (sj >= 0) {       // wave-uniform; the record's base is a scalar, the lane adds its 32-bit byte offset
-        char* rowb = reinterpret_cast<char*>(B.pair_grad) + (size_t)sj * (kPairStride * 4);
-        if ((int)wofs4 >= 0) *reinterpret_cast<float*>(rowb + wofs4) = wextra ? eres : mres;
-      }
+      // wave-uniform; buffer store: the record's offset is a scalar (soffset), the lane adds its 32-bit byte
+      // offset, and a lane without a dword has an offset beyond the buffer's extent, which drops its store
+      // (no per-lane 64-bit address, no exec masking)
+      if (sj >= 0)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(wextra ? eres : mres), pair_rsrc, wofs4, sj * (kPairStride * 4), 0);
       written |= 1ull << j;
     }
   };
@@ -827,6 +833,8 @@ int launch_visibility(const int* n_touched, unsigned char* vis, int n, hipStream
 
 // ---------------------------------------------------------------------------------
 int launch_backward(const KP& P, const KB& B, hipStream_t st, bool skip_tau_reduce) {
+  // k_blend_bwd stores the pair records through a raw buffer descriptor of kPairBufferExtent bytes (53 M pairs)
+  if ((unsigned long long)max(P.cap, 0) * (kPairStride * 4) > kPairBufferExtent) return MGS_ERR_UNSUPPORTED;
   if (B.sketch_mode != 0) {
     const size_t HW = (size_t)P.W * P.H;
     const size_t nacc = (size_t)B.stack_dim * B.sketch_dim * 6;

@@ -958,8 +958,10 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
           const float t2 = __builtin_fmaf(v.y, yh, u.z);
           // the quadratic form is <= 0; the clamp only removes rounding excursions of the expanded
           // form (the reference's "power > 0: skip" can fire on rounding alone, too)
-          const float pw = fminf(0.f, __builtin_fmaf(yh, t2, __builtin_fmaf(xh, t1, u.x)));
-          float a = fminf(kAlphaMax, v.z * __builtin_amdgcn_exp2f(pw));
+          // (exp2 clamped to [0, 1] = exp2 of the exponent clamped at 0, and the clamp is an output modifier
+          // of v_exp_f32: no instruction)
+          const float pw = __builtin_fmaf(yh, t2, __builtin_fmaf(xh, t1, u.x));
+          float a = fminf(kAlphaMax, v.z * exp2_sat(pw));
           a = a >= kAlphaMin ? a : 0.f;
           const float test_T = __builtin_fmaf(-a, T, T);
           // T >= kTStop is invariant on live pixels, so test_T < kTStop implies a > 0: the pixel

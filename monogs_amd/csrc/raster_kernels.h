@@ -90,6 +90,10 @@ struct KB {   // backward extras
 // the XCDs: work per tile varies smoothly over the image and the padded tail is empty).
 // Bijective on a grid padded to a multiple of 8*CHUNK.  Speed only: results do not depend
 // on placement.
+// exp2(min(x, 0)): the quadratic form of a splat is <= 0 and only rounding makes it positive; clamping the
+// RESULT to [0, 1] is the same function and folds into v_exp_f32's clamp output modifier.
+__device__ __forceinline__ float exp2_sat(float x) { return __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(x), 0.f, 1.f); }
+
 template <int CHUNK>
 __device__ __forceinline__ int xcd_remap(int bid) {
   const int xcd = bid & 7, slot = bid >> 3;
@@ -131,6 +135,7 @@ constexpr int kItem = 32;
 // Record of one (tile, Gaussian) pair in pair_grad: (S1, Sx, Sy, Sxx, Sxy, Syy, Rr, Rg, Rb, Rd), 40 B,
 // no padding: k_preprocess_bwd streams a wave's contiguous run of records with coalesced loads.
 constexpr int kPairStride = 10;
+constexpr unsigned int kPairBufferExtent = 0x80000000u;   // k_blend_bwd addresses pair_grad as a raw buffer of this many bytes
 constexpr int kPreChunk = 128;      // records staged per wave and trip in k_preprocess_bwd (5 KB of LDS per wave)
 constexpr int kBinBlocks = 512;    // workgroups of the LDS-privatised binning passes
 constexpr int kBinSmallMap = 65536;  // up to here the binning passes run 256-thread workgroups of 256 Gaussians

@@ -10,7 +10,7 @@ import os, sys, ctypes as C
 import numpy as np
 sys.path.insert(0, "/root/repo")
 import monogs_amd._cabi as cabi
-cabi.LIB_PATH = "/root/repo/scratch/libstamp.so"
+cabi.LIB_PATH = os.environ.get("MGS_STAMP_LIB", "/root/repo/scratch/libstamp.so")
 import torch
 from monogs_amd import rasterizer as R, synthetic as S
 dev = torch.device("cuda:0")
@@ -38,7 +38,11 @@ t0 = a[:, 0].max() - 30000
 keep = a[:, 0] >= t0
 a, ph = a[keep], ph[keep]
 T = len(a)
-nmiss = ph[:, 0] >> 32; nlanes = ph[:, 0] & 0xffffffff; ph[:, 0] = 0
+PH0 = os.environ.get("MGS_STAMP_PH0", "0") == "1"     # library built with -DMGS_STAMP_PH0: phase 0 instead of lane statistics
+if PH0:
+    nmiss = nlanes = np.zeros(T, dtype=np.int64)
+else:
+    nmiss = ph[:, 0] >> 32; nlanes = ph[:, 0] & 0xffffffff; ph[:, 0] = 0
 print("quadrant visits %d, of which no pixel passes %d (%.1f%%); passing lanes per remaining visit %.1f of 64" % (
     (a[:, 2] & 0xffffffff).sum(), nmiss.sum(), 100.0 * nmiss.sum() / max(1, (a[:, 2] & 0xffffffff).sum()),
     nlanes.sum() / max(1, (a[:, 2] & 0xffffffff).sum() - nmiss.sum())))
@@ -52,6 +56,11 @@ print("phase us per item (mean, at %.0f MHz): per-pixel state %.2f  staging %.2f
     clk, ph[:, 0].mean() / clk, ph[:, 1].mean() / clk, ph[:, 2].mean() / clk, nvisit.mean(), nany.mean()))
 live = nvisit > 0
 print("items with work %d: walk us %.2f for %.1f quadrant visits (%.0f cycles per visit)" % (live.sum(), ph[live, 2].mean() / clk, nvisit[live].mean(), ph[live, 2].mean() / max(1.0, nvisit[live].mean())))
+if PH0:
+    cyc = ph[live, 0] + ph[live, 1] + ph[live, 2]
+    print("items with work: dur us %.2f; phase cycles: state %.0f staging %.0f walk %.0f (sum %.0f) -> %.0f MHz if the phases cover the item" % (
+        dur[live].mean(), ph[live, 0].mean(), ph[live, 1].mean(), ph[live, 2].mean(), cyc.mean(), cyc.mean() / dur[live].mean()))
+    print("items without work: phase cycles: state %.0f staging %.0f walk %.0f" % (ph[~live, 0].mean(), ph[~live, 1].mean(), ph[~live, 2].mean()))
 print("items without work %d: dur us %.2f" % ((~live).sum(), dur[~live].mean() if (~live).any() else 0))
 ts = np.linspace(0, end.max(), 14)
 print("resident items at t:", [(round(float(t), 1), int(((start <= t) & (end > t)).sum())) for t in ts])
