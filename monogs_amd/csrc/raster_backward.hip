@@ -95,6 +95,10 @@ constexpr float kLog2eB = 1.4426950408889634f;
 // Orders this wave's LDS writes before its own later LDS reads (the staged records belong to one
 // wave: no workgroup barrier is wanted).  LDS operations of one wave execute in order; the waitcnt +
 // memory clobber keep the compiler from moving accesses across.
+// v_min_f32 without the canonicalising v_max the compiler puts in front of fminf
+// (a: a wave-uniform bound, kept in a scalar register)
+__device__ __forceinline__ float min_f32(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "s"(a), "v"(b)); return r; }
+
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 template <bool SKETCH, bool JONLY = false, bool POSE = false>
@@ -307,48 +311,55 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
       MGS_BLANES(k);
       if (__ballot(k) == 0ull) continue;              // wave-uniform
       any = true;
-      // ak: opacity * G where the splat is blended, else 0; the blended alpha is its clamp at 0.99 and the
-      // gradient flows through the UNclamped product (as upstream: dL/dG = opacity * dL/dalpha)
-      const float ak = k ? ar : 0.f;
-      const float ae = fminf(kAlphaMax, ak);
-      const float w = ae * T[q];
-      const v2f cc = __builtin_elementwise_fma(G2d[q], BD, G01[q] * RG);
-      const float gc = cc.x + cc.y;                   // g . c
-      gS[q] -= w * gc;
-      const float om = 1.f - ae;
-      const float ro = __builtin_amdgcn_rcpf(om);
-      const float dA = T[q] * gc - ro * gS[q];
-      T[q] *= om;
-      const float Wt = ak * dA;
-      const v2f Wxy = v2f{Wt, Wt} * d;                // (W dx, W dy)
-      if constexpr (POSE) {
-        R12 += Wxy;
-        R34 = __builtin_elementwise_fma(v2f{Wxy.x, Wxy.x}, d, R34);
-        r5 = __builtin_fmaf(Wxy.y, d.y, r5);
-        r0 = __builtin_fmaf(w, G2d[q].y, r0);          // Rd (r0 is free in this variant)
-      } else if constexpr (!JONLY) {
-        r0 += Wt;
-        R12 += Wxy;
-        R34 = __builtin_elementwise_fma(v2f{Wxy.x, Wxy.x}, d, R34);
-        r5 = __builtin_fmaf(Wxy.y, d.y, r5);
-        const v2f ww = {w, w};
-        R67 = __builtin_elementwise_fma(ww, G01[q], R67);
-        R89 = __builtin_elementwise_fma(ww, G2d[q], R89);
-      }
-      if constexpr (SKETCH) {
-        jq_mask |= 1u << q;      // wave-uniform: this quadrant's rows are non-zero
-        // J_t += W (c0 dx + c1 dy + c2 dx^2 + c3 dx dy + c4 dy^2) + (w dL/dD) c5 for the six tau
-        // components: the splat's 36 coefficients are staged in LDS in feature-major order, so two
-        // tau components share one packed FMA (18 instead of 36 per quadrant)
-        const float X[6] = {Wxy.x, Wxy.y, Wxy.x * d.x, Wxy.x * d.y, Wxy.y * d.y, w * G2d[q].y};
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-          const v2f xi = {X[i], X[i]};
-#pragma unroll
-          for (int t = 0; t < 3; t++)
-            J2[q][t] = __builtin_elementwise_fma(cf2[3 * i + t], xi, J2[q][t]);
+      // a: opacity * G of the lanes that blend the splat.  The blended alpha is its clamp at 0.99 and the
+      // gradient flows through the UNclamped product (as upstream: dL/dG = opacity * dL/dalpha).
+      auto body = [&](const float a) {
+        const float ae = min_f32(kAlphaMax, a);
+        const float w = ae * T[q];
+        const v2f cc = __builtin_elementwise_fma(G2d[q], BD, G01[q] * RG);
+        const float gc = cc.x + cc.y;                   // g . c
+        gS[q] -= w * gc;
+        const float om = 1.f - ae;
+        const float ro = __builtin_amdgcn_rcpf(om);
+        const float dA = T[q] * gc - ro * gS[q];
+        T[q] *= om;
+        const float Wt = a * dA;
+        const v2f Wxy = v2f{Wt, Wt} * d;                // (W dx, W dy)
+        if constexpr (POSE) {
+          R12 += Wxy;
+          R34 = __builtin_elementwise_fma(v2f{Wxy.x, Wxy.x}, d, R34);
+          r5 = __builtin_fmaf(Wxy.y, d.y, r5);
+          r0 = __builtin_fmaf(w, G2d[q].y, r0);          // Rd (r0 is free in this variant)
+        } else if constexpr (!JONLY) {
+          r0 += Wt;
+          R12 += Wxy;
+          R34 = __builtin_elementwise_fma(v2f{Wxy.x, Wxy.x}, d, R34);
+          r5 = __builtin_fmaf(Wxy.y, d.y, r5);
+          const v2f ww = {w, w};
+          R67 = __builtin_elementwise_fma(ww, G01[q], R67);
+          R89 = __builtin_elementwise_fma(ww, G2d[q], R89);
         }
-      }
+        if constexpr (SKETCH) {
+          jq_mask |= 1u << q;      // wave-uniform: this quadrant's rows are non-zero
+          // J_t += W (c0 dx + c1 dy + c2 dx^2 + c3 dx dy + c4 dy^2) + (w dL/dD) c5 for the six tau
+          // components: the splat's 36 coefficients are staged in LDS in feature-major order, so two
+          // tau components share one packed FMA (18 instead of 36 per quadrant)
+          const float X[6] = {Wxy.x, Wxy.y, Wxy.x * d.x, Wxy.x * d.y, Wxy.y * d.y, w * G2d[q].y};
+#pragma unroll
+          for (int i = 0; i < 6; i++) {
+            const v2f xi = {X[i], X[i]};
+#pragma unroll
+            for (int t = 0; t < 3; t++)
+              J2[q][t] = __builtin_elementwise_fma(cf2[3 * i + t], xi, J2[q][t]);
+          }
+        }
+      };
+      // Quadrant 0 finds the pixel sums at zero and SETS them: written with a select, every lane computes
+      // and a lane that does not blend the splat yields exact zeros (no zeroing per splat on this path).
+      // The other quadrants run under the EXEC mask of the blending lanes - no select; the other lanes' T
+      // and g.S simply stay and the sums receive nothing from them.
+      if (q == 0) body(k ? ar : 0.f);
+      else if (k) body(ar);
     }
     if (!JONLY && any) {
       // the ten wave totals land in ten different lanes; each stores its own dword of the
