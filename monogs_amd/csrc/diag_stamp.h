@@ -74,12 +74,22 @@ struct BwdStamp {
       g_bstamps[4 * blockIdx.x + 3] = ((long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32) |
                                       __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
       for (int k = 1; k < 3; k++) g_bphase[4 * blockIdx.x + k] = ph[k];
+#ifdef MGS_STAMP_FINE
+      g_bphase[4 * blockIdx.x + 3] = ph[3];
+#else
       g_bphase[4 * blockIdx.x + 3] = ((long long)item_base << 32) | (unsigned int)item_id;
+#endif
     }
   }
 };
 #define MGS_BSTAMP BwdStamp bstamp_
+#ifdef MGS_STAMP_FINE   // the item's prologue in four steps (item record | quadrant ends | per-pixel loads | rest of the state phase)
+#define MGS_BMARK(k)
+#define MGS_BFINE(k, wait) do { asm volatile(wait ::: "memory"); bstamp_.mark(k); } while (0)
+#else
 #define MGS_BMARK(k) bstamp_.mark(k)
+#define MGS_BFINE(k, wait)
+#endif
 #define MGS_BCOUNT(v, a) (bstamp_.nvisit += (v), bstamp_.nany += (a))
 #define MGS_BITEM(item, base) (bstamp_.item_id = (item), bstamp_.item_base = (base))
 #define MGS_BLANES(k) (bstamp_.nmiss += (__ballot(k) == 0ull), bstamp_.nlanes += __popcll(__ballot(k)))
@@ -87,6 +97,7 @@ struct BwdStamp {
 #else
 #define MGS_BSTAMP
 #define MGS_BMARK(k)
+#define MGS_BFINE(k, wait)
 #define MGS_BCOUNT(v, a)
 #define MGS_BITEM(item, base)
 #define MGS_BLANES(k)

@@ -159,6 +159,7 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
   // tile, index of the item's first key, number of splats (<= kItem), position in the tile's list.
   const int4 sr = P.seg_rec[item];
   const int tile = sr.x, k0 = sr.y, nb = sr.z, base = sr.w;
+  MGS_BFINE(0, "s_waitcnt lgkmcnt(0)");
   MGS_BITEM(item, base);
   if (nb <= 0) continue;
   if constexpr (SKETCH) {
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
       if (tx * kTile + 8 * (q & 1) >= P.W || ty * kTile + 8 * (q >> 1) >= P.H) qlast[q] = 0;
   }
   const int tile_last = max(max(qlast[0], qlast[1]), max(qlast[2], qlast[3]));
+  MGS_BFINE(1, "s_waitcnt lgkmcnt(0)");
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     g0[q] = g1[q] = g2[q] = gd[q] = 0.f;
@@ -238,6 +240,7 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
         k3[q] = ck[1024 + p];
       }
     }
+    MGS_BFINE(2, "s_waitcnt vmcnt(0)");
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -259,6 +262,7 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
   }
 
   MGS_BMARK(0);
+  MGS_BFINE(3, "");
   // reduce-scatter bookkeeping (wave_reduce.h): which of the ten sums this lane ends up with
   const unsigned long long b3mask = __ballot((lane & 8) != 0);
   const bool wextra = lane == 31 || lane == 63;

@@ -56,7 +56,13 @@ print("phase us per item (mean, at %.0f MHz): per-pixel state %.2f  staging %.2f
     clk, ph[:, 0].mean() / clk, ph[:, 1].mean() / clk, ph[:, 2].mean() / clk, nvisit.mean(), nany.mean()))
 live = nvisit > 0
 print("items with work %d: walk us %.2f for %.1f quadrant visits (%.0f cycles per visit)" % (live.sum(), ph[live, 2].mean() / clk, nvisit[live].mean(), ph[live, 2].mean() / max(1.0, nvisit[live].mean())))
-if PH0:
+FINE = os.environ.get("MGS_STAMP_FINE", "0") == "1"   # library built with -DMGS_STAMP_PH0 -DMGS_STAMP_FINE: the prologue in four steps
+if FINE:
+    names = ("item record", "quadrant ends", "per-pixel loads", "rest of the state phase")
+    for sel, what in ((live, "items with work"), (~live, "items without work")):
+        print(what + ": cycles " + ", ".join("%s %.0f" % (n, ph[sel, k].mean()) for k, n in enumerate(names)) +
+              "; item dur us %.2f" % dur[sel].mean())
+elif PH0:
     cyc = ph[live, 0] + ph[live, 1] + ph[live, 2]
     print("items with work: dur us %.2f; phase cycles: state %.0f staging %.0f walk %.0f (sum %.0f) -> %.0f MHz if the phases cover the item" % (
         dur[live].mean(), ph[live, 0].mean(), ph[live, 1].mean(), ph[live, 2].mean(), cyc.mean(), cyc.mean() / dur[live].mean()))
