@@ -640,8 +640,20 @@ __global__ __launch_bounds__(kPreBlock) void k_preprocess_bwd(KP P, KB B) {
     for (int c = S0; c < S1; c += kPreChunk) {                   // wave-uniform
       const int n = min(kPreChunk, S1 - c) * (kPairStride / 2);  // 8-B words of this trip
       const size_t w0 = (size_t)c * (kPairStride / 2);
-#pragma unroll 2
-      for (int i = lane; i < n; i += 64) stage[i] = src[w0 + i];
+      // every load of the trip is in flight before the first one is stored (a rolled loop waited for each
+      // pair of loads in turn: five memory round trips per trip instead of one)
+      constexpr int kWords = kPreChunk * (kPairStride / 2) / 64;   // 8-B words per lane and trip
+      float2 w[kWords];
+#pragma unroll
+      for (int u = 0; u < kWords; u++) {
+        const int i = lane + 64 * u;
+        w[u] = src[w0 + min(i, n - 1)];        // clamped: the last trip is ragged, the load stays unconditional
+      }
+#pragma unroll
+      for (int u = 0; u < kWords; u++) {
+        const int i = lane + 64 * u;
+        if (i < n) stage[i] = w[u];
+      }
       wave_lds_fence();
       const int a0 = max(s0, c), a1 = min(s1, c + kPreChunk);
       for (int sl = a0; sl < a1; sl++) {
