@@ -144,28 +144,42 @@ MGS_HD void ewa_cov2d(const Camera& cam, const float pc[3], const float c6[6], C
 }
 
 // Degree-0..3 SH colour for unit direction d; sh is [K][3].
+// The coefficients of a band are read for all three channels at once, before they are used (on the GPU: one
+// batch of independent loads per band; a loop over the channels with the bands nested inside it waited for
+// memory once per channel and band - three round trips at degree 0, twelve at degree 3).  The arithmetic per
+// channel is the left-to-right sum it always was.
 MGS_HD void sh_to_rgb(int deg, const float* sh, const float d[3], float rgb[3]) {
   const float x = d[0], y = d[1], z = d[2];
-  for (int c = 0; c < 3; c++) {
-    float res = SH_C0 * sh[c];
-    if (deg > 0) {
-      res = res - SH_C1 * y * sh[3 + c] + SH_C1 * z * sh[6 + c] - SH_C1 * x * sh[9 + c];
-      if (deg > 1) {
-        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-        res = res + SH_C2_0 * xy * sh[12 + c] + SH_C2_1 * yz * sh[15 + c] +
-              SH_C2_2 * (2.f * zz - xx - yy) * sh[18 + c] + SH_C2_3 * xz * sh[21 + c] +
-              SH_C2_4 * (xx - yy) * sh[24 + c];
-        if (deg > 2) {
-          res = res + SH_C3_0 * y * (3.f * xx - yy) * sh[27 + c] + SH_C3_1 * xy * z * sh[30 + c] +
-                SH_C3_2 * y * (4.f * zz - xx - yy) * sh[33 + c] +
-                SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy) * sh[36 + c] +
-                SH_C3_4 * x * (4.f * zz - xx - yy) * sh[39 + c] +
-                SH_C3_5 * z * (xx - yy) * sh[42 + c] + SH_C3_6 * x * (xx - 3.f * yy) * sh[45 + c];
-        }
+  float res[3];
+  {
+    const float s0 = sh[0], s1 = sh[1], s2 = sh[2];
+    res[0] = SH_C0 * s0; res[1] = SH_C0 * s1; res[2] = SH_C0 * s2;
+  }
+  if (deg > 0) {
+    float b1[9];
+    for (int i = 0; i < 9; i++) b1[i] = sh[3 + i];
+    for (int c = 0; c < 3; c++) res[c] = res[c] - SH_C1 * y * b1[c] + SH_C1 * z * b1[3 + c] - SH_C1 * x * b1[6 + c];
+    if (deg > 1) {
+      const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      float b2[15];
+      for (int i = 0; i < 15; i++) b2[i] = sh[12 + i];
+      for (int c = 0; c < 3; c++)
+        res[c] = res[c] + SH_C2_0 * xy * b2[c] + SH_C2_1 * yz * b2[3 + c] +
+                 SH_C2_2 * (2.f * zz - xx - yy) * b2[6 + c] + SH_C2_3 * xz * b2[9 + c] +
+                 SH_C2_4 * (xx - yy) * b2[12 + c];
+      if (deg > 2) {
+        float b3[21];
+        for (int i = 0; i < 21; i++) b3[i] = sh[27 + i];
+        for (int c = 0; c < 3; c++)
+          res[c] = res[c] + SH_C3_0 * y * (3.f * xx - yy) * b3[c] + SH_C3_1 * xy * z * b3[3 + c] +
+                   SH_C3_2 * y * (4.f * zz - xx - yy) * b3[6 + c] +
+                   SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy) * b3[9 + c] +
+                   SH_C3_4 * x * (4.f * zz - xx - yy) * b3[12 + c] +
+                   SH_C3_5 * z * (xx - yy) * b3[15 + c] + SH_C3_6 * x * (xx - 3.f * yy) * b3[18 + c];
       }
     }
-    rgb[c] = res;
   }
+  rgb[0] = res[0]; rgb[1] = res[1]; rgb[2] = res[2];
 }
 
 // Tile rectangle [min,max) of a splat of integer radius at pixel (x,y).
