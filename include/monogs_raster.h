@@ -37,7 +37,8 @@ typedef enum mgs_status {
   MGS_OK = 0,
   MGS_ERR_BAD_ARGUMENT = -1,   /* null pointer / non-positive size / bad degree */
   MGS_ERR_LAUNCH = -2,         /* hipGetLastError() after a launch was not hipSuccess */
-  MGS_ERR_UNSUPPORTED = -3,
+  MGS_ERR_UNSUPPORTED = -3,    /* a size the kernels are not built for (e.g. a backward with pair_capacity > 53 687 091:
+                                  the pair records are addressed through a 2-GiB buffer descriptor) */
 } mgs_status;
 
 /* Problem shape shared by forward and backward. */
@@ -211,7 +212,8 @@ int32_t mgs_raster_forward_project(const mgs_forward_args* args, void* stream);
  * Safe for any pair_capacity; results are complete iff D <= pair_capacity. */
 int32_t mgs_raster_forward_blend(const mgs_forward_args* args, void* stream);
 
-/* Backward of the whole rasteriser (re-entrant: reads geom/bins, never writes them). */
+/* Backward of the whole rasteriser (re-entrant: reads geom/bins, never writes them).
+ * MGS_ERR_UNSUPPORTED when shape.pair_capacity * 40 B exceeds 2 GiB. */
 int32_t mgs_raster_backward(const mgs_backward_args* args, void* stream);
 
 /* simple-knn: out[i] = mean of the 3 smallest squared distances from points[i] to
