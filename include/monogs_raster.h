@@ -437,9 +437,11 @@ int32_t mgs_camera_from_pose(const float* T, const float* projection, float* vie
 /* One first-order monocular tracking iteration, enqueued as a fixed launch sequence with
  * no host round trip (the Python loop body costs ~1 ms of host time per iteration):
  *   camera matrices from T -> rasteriser forward (project + blend at the caller's fixed
- *   pair capacity) -> tracking objective (mgs_tracking_loss_*) -> pose-only rasteriser
+ *   pair capacity); the blend pass evaluates the tracking objective in its epilogue (the arithmetic of
+ *   mgs_tracking_loss_onepass: d loss / d image into grad_image, the four sums as one partial per 8x8-pixel
+ *   quadrant in the geom workspace - loss.partial is not used by this entry) -> pose-only rasteriser
  *   backward -> Adam on (rot, trans, exposure a, b) + update_pose (mgs_pose_adam_step), with
- *   the small reduction kernels and the 1 / loss of the norm folded into their consumers (10 launches).
+ *   the small reduction kernels and the 1 / loss of the norm folded into their consumers (9 launches).
  * fwd.viewmatrix / fwd.projmatrix / fwd.campos must point at caller-owned device buffers
  * (16/16/>=3 floats; campos may alias viewmatrix) that this call REWRITES from T;
  * fwd.projmatrix_raw is the projection.  The forward is complete iff counters[0] (pair

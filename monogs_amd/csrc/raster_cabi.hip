@@ -57,6 +57,7 @@ int fill_kp(const mgs_forward_args& a, bool need_bins, bool need_outputs, KP& P)
       (!a.out_color || !a.out_depth || !a.out_opacity || !a.radii || !a.n_touched))
     return MGS_ERR_BAD_ARGUMENT;
   const Layout L = make_layout(s);
+  P.obj = KObj{};
   P.N = s.num_gaussians; P.W = s.width; P.H = s.height;
   P.grid_x = (s.width + kTile - 1) / kTile; P.grid_y = (s.height + kTile - 1) / kTile;
   P.T = P.grid_x * P.grid_y;
@@ -247,9 +248,9 @@ int32_t mgs_tracking_iteration(const mgs_tracking_iter_args* args, void* stream)
       !args->one || !args->adam.T || !args->fwd.viewmatrix || !args->fwd.projmatrix)
     return MGS_ERR_BAD_ARGUMENT;
   if (args->fwd.shape.pair_capacity < 1) return MGS_ERR_BAD_ARGUMENT;
-  // 10 launches: camera matrices (unless the caller says they are valid - the previous
-  // iteration's Adam kernel has already written them), 5 forward, 1 loss (un-normalised gradients),
-  // 2 backward, 1 Adam + update_pose (which also sums the tau / exposure / squared-residual block
+  // 9 launches: camera matrices (unless the caller says they are valid - the previous
+  // iteration's Adam kernel has already written them), 5 forward (the last one also evaluates the objective:
+  // un-normalised gradients + partial sums), 2 backward, 1 Adam + update_pose (which also sums the tau / exposure / squared-residual block
   // partials, applies the 1 / loss of the norm and refreshes the camera matrices).
   int32_t rc = MGS_OK;
   if (!args->camera_matrices_valid) {
@@ -258,13 +259,22 @@ int32_t mgs_tracking_iteration(const mgs_tracking_iter_args* args, void* stream)
     if (rc != MGS_OK) return rc;
   }
   if ((rc = mgs_raster_forward_project(&args->fwd, stream)) != MGS_OK) return rc;
-  if ((rc = mgs_raster_forward_blend(&args->fwd, stream)) != MGS_OK) return rc;
+  // The objective rides in the epilogue of the forward blend (raster_kernels.h: KObj): the quadrant wave that
+  // finishes a pixel forms its residual, writes d(loss)/d(image) and leaves its sums as one partial per wave
+  // in the geom workspace - no loss launch between the forward and the backward.
   mgs_tracking_loss_args L = args->loss;
-  L.image = args->fwd.out_color; L.opacity = args->fwd.out_opacity;
-  L.grad_out = args->one; L.grad_image = args->grad_image;
-  L.grad_a = args->grad_exposure; L.grad_b = args->grad_exposure + 1;
-  int32_t nblk = 0;
-  if ((rc = mgs_tracking_loss_onepass(&L, &nblk, stream)) != MGS_OK) return rc;
+  if (!L.gt || !L.exposure_a || !L.exposure_b || !L.scalars) return MGS_ERR_BAD_ARGUMENT;
+  KP P;
+  if ((rc = fill_kp(args->fwd, true, true, P)) != MGS_OK) return rc;
+  const Layout lay = make_layout(args->fwd.shape);
+  float* obj_partial = reinterpret_cast<float*>(static_cast<char*>(args->fwd.geom) + lay.obj_partial);
+  P.obj.on = 1;
+  P.obj.exposure_eps = L.exposure_eps; P.obj.huber_delta = L.huber_delta;
+  P.obj.gt = L.gt; P.obj.mask = L.mask; P.obj.exposure_a = L.exposure_a; P.obj.exposure_b = L.exposure_b;
+  P.obj.grad_image = args->grad_image; P.obj.partial = obj_partial;
+  if ((rc = launch_forward_blend(P, (hipStream_t)stream)) != MGS_OK) return rc;
+  L.partial = obj_partial;
+  const int32_t nblk = 4 * P.T;
   mgs_backward_args B;
   memset(&B, 0, sizeof(B));
   B.fwd = args->fwd;

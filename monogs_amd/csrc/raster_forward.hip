@@ -21,6 +21,7 @@
 
 #include "launch.h"
 #include "raster_kernels.h"
+#include "objective_math.h"
 #define MGS_DIAG_FORWARD
 #include "diag_stamp.h"
 
@@ -820,6 +821,8 @@ __device__ __forceinline__ void mask_clear_bit(unsigned long long& m, int j) {
 }
 
 
+// OBJ: the tracking objective in the epilogue (raster_kernels.h: KObj).
+template <bool OBJ>
 __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
   MGS_STAMP_SCOPE;
   // per staged splat 48 B: (a0, a1, a2, A) (B, C, opacity, -) (r, g, b, depth)
@@ -829,7 +832,12 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
   const int tile = item >> 2, quad = item & 3, lane = threadIdx.x;
   const int tx = tile % P.grid_x, ty = tile / P.grid_x;
   const int qx0 = tx * kTile + 8 * (quad & 1), qy0 = ty * kTile + 8 * (quad >> 1);
-  if (qx0 >= P.W || qy0 >= P.H) return;                  // quadrant outside the image
+  if (qx0 >= P.W || qy0 >= P.H) {                        // quadrant outside the image
+    if constexpr (OBJ) {                                 // ... still owns an entry of the objective's partial sums
+      if (lane < 4) P.obj.partial[(size_t)lane * 4 * P.T + item] = 0.f;
+    }
+    return;
+  }
   const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
   const int ptile = quad * 64 + lane;                    // pixel index in the tile, quadrant-major
   const bool inside = px < P.W && py < P.H;
@@ -1055,6 +1063,48 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
     P.out_depth[pix] = C2D.y;
     P.out_opacity[pix] = 1.f - T;
   }
+  if constexpr (OBJ) {
+    // Tracking objective || Huber(opacity * mask * ((|a| + eps) * image + b - gt)) ||_2, one pixel per lane:
+    // the per-sample arithmetic of k_track_loss_onepass (tracking.hip), channel by channel; d(loss)/d(image)
+    // WITHOUT the 1 / loss of the norm (k_pose_adam_update applies it to the pose gradient, which is linear in
+    // it).  The wave's four sums become partial entry `item` (= 4 tile + quadrant).
+    float acc = 0.f, ga = 0.f, gb = 0.f, l1 = 0.f;
+    const float a = P.obj.exposure_a[0];
+    if (px_e < P.W && py_e < P.H) {
+      const size_t HW = (size_t)P.W * P.H;
+      const size_t pix = (size_t)py_e * P.W + px_e;
+      const float gain = fabsf(a) + P.obj.exposure_eps, bias = P.obj.exposure_b[0];
+      const float om = (1.f - T) * (P.obj.mask ? P.obj.mask[pix] : 1.f);
+      const float im[3] = {C01.x + T * P.bg[0], C01.y + T * P.bg[1], C2D.x + T * P.bg[2]};
+      float gt[3];
+#pragma unroll
+      for (int c = 0; c < 3; c++) gt[c] = P.obj.gt[c * HW + pix];
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        float dh;
+        const float r = om * (gain * im[c] + bias - gt[c]);
+        l1 += fabsf(r);
+        const float h = huber(r, P.obj.huber_delta, dh);
+        acc += h * h;
+        const float gr = h * dh * om;
+        ga += gr * im[c];
+        gb += gr;
+        P.obj.grad_image[c * HW + pix] = gr * gain;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      acc += __shfl_down(acc, off); ga += __shfl_down(ga, off); gb += __shfl_down(gb, off); l1 += __shfl_down(l1, off);
+    }
+    if (lane == 0) {
+      const size_t n = 4 * (size_t)P.T;
+      const float sgn = a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f);
+      P.obj.partial[item] = acc;
+      P.obj.partial[n + item] = ga * sgn;
+      P.obj.partial[2 * n + item] = gb;
+      P.obj.partial[3 * n + item] = l1;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------
@@ -1138,7 +1188,8 @@ int launch_forward_blend(const KP& P, hipStream_t st) {
     launch("tile_sort", k_tile_sort_reg<false>, dim3(P.T), dim3(256), st, P);
     if (P.big_pass) launch("tile_sort_big", k_tile_sort<4096, 1024, false, 1024>, dim3(min(P.T, 512)), dim3(1024), st, P);
   }
-  launch("blend_fwd", k_blend_fwd, dim3(grid_pad(4 * P.T, kFwdChunk)), dim3(64), st, P);
+  if (P.obj.on) launch("blend_fwd", k_blend_fwd<true>, dim3(grid_pad(4 * P.T, kFwdChunk)), dim3(64), st, P);
+  else launch("blend_fwd", k_blend_fwd<false>, dim3(grid_pad(4 * P.T, kFwdChunk)), dim3(64), st, P);
   return check_launch();
 }
 

@@ -11,6 +11,19 @@ namespace mgs {
 
 // One struct carries everything a forward or backward kernel may need; it is passed
 // by value (kernarg segment -> SGPRs).
+// Tracking objective evaluated in the forward blend's epilogue (native first-order tracking iteration only:
+// mgs_tracking_iteration).  The quadrant wave that has just finished a pixel holds its colour and opacity in
+// registers; it forms the residual of tracking.hip's k_track_loss_onepass there, writes d(loss)/d(image) for the
+// backward and leaves its four sums as ONE partial per quadrant wave - the loss launch between the forward and
+// the backward is gone.
+struct KObj {
+  int on;
+  float exposure_eps, huber_delta;
+  const float *gt, *mask, *exposure_a, *exposure_b;   // gt [3][H*W]; mask [H*W] or null
+  float* grad_image;                                  // [3][H*W]
+  float* partial;                                     // [4][4T]: sum h^2 | d/da | d/db | sum |r|, one entry per quadrant wave
+};
+
 struct KP {
   int N, W, H, grid_x, grid_y, T, deg, K, cap;
   int pack;                // 1: sort key low word = id << kPackBits | pair index (no payload array)
@@ -53,6 +66,7 @@ struct KP {
                            // global-atomics fallback): block_prefix[idx / per_block] + pair_off[idx] = first slot
   int big_pass;            // 1: tiles of more than 1024 pairs are left to the second sort launch
   int clamp_up;            // backward: mgs_backward_args.clamp_gradient_mode
+  KObj obj;                // forward blend: objective in the epilogue (off unless the tracking iteration sets it)
 };
 
 struct KM {   // mapping mode of the preprocess backward (mgs_map_accum_args)
@@ -108,7 +122,7 @@ inline uint64_t align_up(uint64_t v) { return (v + kAlign - 1) / kAlign * kAlign
 
 struct Layout {
   uint64_t rec, pair_count, pair_off, hit_mask, block_prefix, scan_tmp, tile_count, tile_offset, tile_cursor, bin_table, final_TC, final_DL,
-      quad_last, seg_offset, counters, geom_bytes;
+      quad_last, seg_offset, obj_partial, counters, geom_bytes;
   uint64_t keys, payload, seg_rec, ckpt, max_segs, bins_bytes;
   uint64_t pair_grad, tau_partial, bwd_bytes;
   uint64_t pix_jac, splat_jac, sketch_bytes;
@@ -169,6 +183,7 @@ inline Layout make_layout(const mgs_raster_shape& s) {
   L.final_DL = o; o = align_up(o + T * 256 * 8);
   L.quad_last = o; o = align_up(o + T * 4 * 4);
   L.seg_offset = o; o = align_up(o + (T + 1) * 4);
+  L.obj_partial = o; o = align_up(o + T * 16 * 4);      // KObj::partial: 4 sums x 4T quadrant waves
   L.counters = o; o = align_up(o + 16);
   L.geom_bytes = o;
   o = 0;

@@ -13,6 +13,7 @@
 
 #include "../../include/monogs_raster.h"
 #include "launch.h"
+#include "objective_math.h"
 
 namespace mgs {
 
@@ -50,7 +51,30 @@ __global__ __launch_bounds__(512) void k_pose_adam_update(mgs_pose_adam_args A) 
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     if (lane == 0) s_g[wave < 3 ? 3 + wave : wave - 3] = v;      // tau = [rho (trans); theta (rot)]
   }
-  if (A.exposure_partials && wave >= 6) {
+  // Many partials (the objective evaluated in the forward's epilogue leaves one per quadrant wave, 4T of them):
+  // all 512 threads sum the four arrays together - every load of a thread independent, a wave sum, the eight
+  // wave totals added in a fixed order by thread 0 below - instead of one wave walking each array.
+  const bool coop = A.loss_partials && A.exposure_partials && A.loss_norm_mode == 1 && A.num_loss_partials > 1024 &&
+                    A.num_exposure_partials == A.num_loss_partials &&
+                    (!A.l1_partials || A.num_l1_partials == A.num_loss_partials);
+  __shared__ float s_coop[4][8];
+  if (coop) {
+    const int n = A.num_loss_partials;
+    const float* l1p = (A.l1_partials && A.best) ? A.l1_partials : nullptr;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+#pragma unroll 5
+    for (int i = threadIdx.x; i < n; i += 512) {
+      v0 += A.loss_partials[i];
+      v1 += A.exposure_partials[i];
+      v2 += A.exposure_partials[n + i];
+      if (l1p) v3 += l1p[i];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      v0 += __shfl_down(v0, off); v1 += __shfl_down(v1, off); v2 += __shfl_down(v2, off); v3 += __shfl_down(v3, off);
+    }
+    if (lane == 0) { s_coop[0][wave] = v0; s_coop[1][wave] = v1; s_coop[2][wave] = v2; s_coop[3][wave] = v3; }
+  }
+  if (!coop && A.exposure_partials && wave >= 6) {
     const int c = wave - 6;
     float v = 0.f;
 #pragma unroll 8
@@ -59,7 +83,7 @@ __global__ __launch_bounds__(512) void k_pose_adam_update(mgs_pose_adam_args A) 
     if (lane == 0) s_g[6 + c] = v;
   }
   __shared__ float s_loss[2];
-  if (A.loss_partials && wave >= 6 && (A.loss_norm_mode == 0 || wave == 6)) {   // colour / depth block sums, or sum h^2
+  if (!coop && A.loss_partials && wave >= 6 && (A.loss_norm_mode == 0 || wave == 6)) {   // colour / depth block sums, or sum h^2
     const int c = wave - 6;
     float v = 0.f;
 #pragma unroll 8
@@ -68,7 +92,7 @@ __global__ __launch_bounds__(512) void k_pose_adam_update(mgs_pose_adam_args A) 
     if (lane == 0) s_loss[c] = v;
   }
   __shared__ float s_l1;
-  if (A.l1_partials && A.best && wave == 5) {       // (wave 5 has also summed a tau component: both are short)
+  if (!coop && A.l1_partials && A.best && wave == 5) {       // (wave 5 has also summed a tau component: both are short)
     float v = 0.f;
 #pragma unroll 8
     for (int i = lane; i < A.num_l1_partials; i += 64) v += A.l1_partials[i];
@@ -77,6 +101,16 @@ __global__ __launch_bounds__(512) void k_pose_adam_update(mgs_pose_adam_args A) 
   }
   __syncthreads();
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (coop) {
+    float t[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      t[c] = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; w++) t[c] += s_coop[c][w];
+    }
+    s_loss[0] = t[0]; s_g[6] = t[1]; s_g[7] = t[2]; s_l1 = t[3];
+  }
   if (A.sticky_converged && A.converged && *A.converged != 0) return;    // the reference has left its loop
   float grad_scale = 1.f;
   if (A.loss_partials && A.loss_norm_mode == 1) {
@@ -206,14 +240,6 @@ __global__ void k_camera_from_pose(const float* T, const float* proj, float* vie
 // ---------------------------------------------------------------------------------
 constexpr int kLossBlock = 256;
 constexpr int kLossBlocks = 512;
-
-__device__ __forceinline__ float huber(float x, float delta, float& dh) {
-  const float ax = fabsf(x);
-  if (delta <= 0.f || ax < delta) { dh = 1.f; return x; }
-  const float s = sqrtf(2.f * delta * ax - delta * delta);
-  dh = delta / s;
-  return copysignf(s, x);
-}
 
 __device__ __forceinline__ float block_sum(float v, float* s_red) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
