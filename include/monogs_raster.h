@@ -666,10 +666,8 @@ int32_t mgs_map_activate(const mgs_map_activate_args* args, void* stream);
 
 /* One view of one mapping iteration as a fixed launch sequence with no host round trip
  * (the body of the loops at utils/slam_backend.py:183-242 plus this view's share of :247-332):
- *   camera matrices from T -> rasteriser forward at the caller's fixed pair capacity; the blend pass
- *   evaluates the mapping objective (utils/slam_utils.py:224-253: the arithmetic of mgs_mapping_loss_fused
- *   with upstream gradient 1) in its epilogue - gradients into grad_image / grad_depth, the four sums as one
- *   partial per 8x8-pixel quadrant in the geom workspace ->
+ *   camera matrices from T -> rasteriser forward at the caller's fixed pair capacity ->
+ *   mapping objective (utils/slam_utils.py:224-253) value + gradients in one pass ->
  *   rasteriser backward in mapping mode (mgs_map_accum_args: gradients chained through the
  *   activations and ACCUMULATED over the views, densification statistics, occ-aware visibility)
  *   -> Adam on this view's (cam_rot_delta, cam_trans_delta, exposure_a, exposure_b) + update_pose
@@ -677,7 +675,8 @@ int32_t mgs_map_activate(const mgs_map_activate_args* args, void* stream);
  *   with the other views).
  * forward_only != 0 stops after the forward and only writes accum.visibility (the prune pass of
  * :259-290 consumes nothing else).  loss.image / depth / grad_* / partial and adam.grad_* /
- * *_partials are filled in by the call (loss.partial is not used by this entry). */
+ * *_partials are filled in by the call; loss.partial must hold
+ * mgs_mapping_loss_partial_count(HW) floats. */
 typedef struct mgs_mapping_view_args {
   mgs_forward_args fwd;
   void* bwd;                     /* bwd_bytes of backward scratch */

@@ -1,4 +1,4 @@
-// Per-sample arithmetic of the tracking / mapping objectives, shared by tracking.hip's loss kernels and the objective
+// Per-sample arithmetic of the tracking objective, shared by tracking.hip's loss kernels and the objective
 // epilogue of k_blend_fwd (raster_forward.hip): both must form the same residual bit for bit.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -14,7 +14,5 @@ __device__ __forceinline__ float huber(float x, float delta, float& dh) {
   dh = delta / s;
   return copysignf(s, x);
 }
-
-__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
 
 }  // namespace mgs

@@ -268,7 +268,7 @@ int32_t mgs_tracking_iteration(const mgs_tracking_iter_args* args, void* stream)
   if ((rc = fill_kp(args->fwd, true, true, P)) != MGS_OK) return rc;
   const Layout lay = make_layout(args->fwd.shape);
   float* obj_partial = reinterpret_cast<float*>(static_cast<char*>(args->fwd.geom) + lay.obj_partial);
-  P.obj.kind = 1;
+  P.obj.on = 1;
   P.obj.exposure_eps = L.exposure_eps; P.obj.huber_delta = L.huber_delta;
   P.obj.gt = L.gt; P.obj.mask = L.mask; P.obj.exposure_a = L.exposure_a; P.obj.exposure_b = L.exposure_b;
   P.obj.grad_image = args->grad_image; P.obj.partial = obj_partial;
@@ -301,7 +301,7 @@ int32_t mgs_tracking_iteration(const mgs_tracking_iter_args* args, void* stream)
 int32_t mgs_mapping_view_iteration(const mgs_mapping_view_args* args, void* stream) {
   if (!args || !args->adam.T || !args->fwd.viewmatrix || !args->fwd.projmatrix || args->fwd.shape.pair_capacity < 1)
     return MGS_ERR_BAD_ARGUMENT;
-  if (!args->forward_only && (!args->bwd || !args->grad_image || !args->grad_tau || !args->loss.gt))
+  if (!args->forward_only && (!args->bwd || !args->grad_image || !args->grad_tau || !args->loss.partial || !args->loss.gt))
     return MGS_ERR_BAD_ARGUMENT;
   int32_t rc = MGS_OK;
   if (!args->camera_matrices_valid) {
@@ -310,33 +310,21 @@ int32_t mgs_mapping_view_iteration(const mgs_mapping_view_args* args, void* stre
     if (rc != MGS_OK) return rc;
   }
   if ((rc = mgs_raster_forward_project(&args->fwd, stream)) != MGS_OK) return rc;
+  if ((rc = mgs_raster_forward_blend(&args->fwd, stream)) != MGS_OK) return rc;
   if (args->forward_only) {
-    if ((rc = mgs_raster_forward_blend(&args->fwd, stream)) != MGS_OK) return rc;
     if (args->accum.visibility) {
       return launch_visibility((const int*)args->fwd.n_touched, args->accum.visibility,
                                args->fwd.shape.num_gaussians, (hipStream_t)stream);
     }
     return MGS_OK;
   }
-  // objective: value + gradients in the epilogue of the forward blend (raster_kernels.h: KObj, kind 2); the
-  // per-quadrant sums are consumed by the Adam kernel
+  // objective: value + gradients in one pass; the block sums are consumed by the Adam kernel
   mgs_mapping_loss_args L = args->loss;
-  if (L.apply_exposure && (!L.exposure_a || !L.exposure_b)) return MGS_ERR_BAD_ARGUMENT;
-  if (L.w_depth != 0.f && (!L.gt_depth || !args->grad_depth)) return MGS_ERR_BAD_ARGUMENT;
-  L.grad_depth = L.w_depth != 0.f ? args->grad_depth : nullptr;
-  KP P;
-  if ((rc = fill_kp(args->fwd, true, true, P)) != MGS_OK) return rc;
-  const Layout lay = make_layout(args->fwd.shape);
-  float* obj_partial = reinterpret_cast<float*>(static_cast<char*>(args->fwd.geom) + lay.obj_partial);
-  P.obj.kind = 2;
-  P.obj.exposure_eps = L.exposure_eps; P.obj.apply_exposure = L.apply_exposure;
-  P.obj.w_rgb = L.w_rgb; P.obj.w_depth = L.w_depth; P.obj.depth_mask_threshold = L.depth_mask_threshold;
-  P.obj.gt = L.gt; P.obj.mask = L.mask; P.obj.exposure_a = L.exposure_a; P.obj.exposure_b = L.exposure_b;
-  P.obj.gt_depth = L.gt_depth;
-  P.obj.grad_image = args->grad_image; P.obj.grad_depth = L.grad_depth; P.obj.partial = obj_partial;
-  if ((rc = launch_forward_blend(P, (hipStream_t)stream)) != MGS_OK) return rc;
-  L.partial = obj_partial;
-  const int32_t nblk = 4 * P.T;
+  L.image = args->fwd.out_color; L.depth = args->fwd.out_depth;
+  L.grad_image = args->grad_image; L.grad_depth = L.w_depth != 0.f ? args->grad_depth : nullptr;
+  L.grad_out = nullptr;
+  int32_t nblk = 0;
+  if ((rc = mgs_mapping_loss_fused(&L, &nblk, stream)) != MGS_OK) return rc;
   // full backward in mapping mode
   mgs_backward_args B;
   memset(&B, 0, sizeof(B));

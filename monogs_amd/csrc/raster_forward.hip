@@ -821,8 +821,8 @@ __device__ __forceinline__ void mask_clear_bit(unsigned long long& m, int j) {
 }
 
 
-// OBJ: objective in the epilogue (raster_kernels.h: KObj::kind).
-template <int OBJ>
+// OBJ: the tracking objective in the epilogue (raster_kernels.h: KObj).
+template <bool OBJ>
 __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
   MGS_STAMP_SCOPE;
   // per staged splat 48 B: (a0, a1, a2, A) (B, C, opacity, -) (r, g, b, depth)
@@ -833,7 +833,7 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
   const int tx = tile % P.grid_x, ty = tile / P.grid_x;
   const int qx0 = tx * kTile + 8 * (quad & 1), qy0 = ty * kTile + 8 * (quad >> 1);
   if (qx0 >= P.W || qy0 >= P.H) {                        // quadrant outside the image
-    if constexpr (OBJ != 0) {                            // ... still owns an entry of the objective's partial sums
+    if constexpr (OBJ) {                                 // ... still owns an entry of the objective's partial sums
       if (lane < 4) P.obj.partial[(size_t)lane * 4 * P.T + item] = 0.f;
     }
     return;
@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
     P.out_depth[pix] = C2D.y;
     P.out_opacity[pix] = 1.f - T;
   }
-  if constexpr (OBJ == 1) {
+  if constexpr (OBJ) {
     // Tracking objective || Huber(opacity * mask * ((|a| + eps) * image + b - gt)) ||_2, one pixel per lane:
     // the per-sample arithmetic of k_track_loss_onepass (tracking.hip), channel by channel; d(loss)/d(image)
     // WITHOUT the 1 / loss of the norm (k_pose_adam_update applies it to the pose gradient, which is linear in
@@ -1103,56 +1103,6 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
       P.obj.partial[n + item] = ga * sgn;
       P.obj.partial[2 * n + item] = gb;
       P.obj.partial[3 * n + item] = l1;
-    }
-  }
-  if constexpr (OBJ == 2) {
-    // Mapping objective w_rgb mean|mask ((|a| + eps) image + b - gt)| + w_depth mean|depth_mask (depth - gt_depth)|,
-    // one pixel per lane: the per-sample arithmetic of k_map_loss_fused (tracking.hip) with dL/dloss = 1, the
-    // three colours and then the depth; partial entry `item` = (sum |r_colour|, sum |r_depth|, d/da, d/db).
-    float sc = 0.f, sd = 0.f, ga = 0.f, gb = 0.f;
-    const float a = P.obj.apply_exposure ? P.obj.exposure_a[0] : 1.f;
-    if (px_e < P.W && py_e < P.H) {
-      const size_t HW = (size_t)P.W * P.H;
-      const size_t pix = (size_t)py_e * P.W + px_e;
-      const float gain = P.obj.apply_exposure ? fabsf(a) + P.obj.exposure_eps : 1.f;
-      const float bias = P.obj.apply_exposure ? P.obj.exposure_b[0] : 0.f;
-      const float hw = (float)HW;
-      const float kc = P.obj.w_rgb / (3.f * hw), kd = P.obj.w_depth / hw;
-      const float m = P.obj.mask ? P.obj.mask[pix] : 1.f;
-      const float im[3] = {C01.x + T * P.bg[0], C01.y + T * P.bg[1], C2D.x + T * P.bg[2]};
-      float gt[3];
-#pragma unroll
-      for (int c = 0; c < 3; c++) gt[c] = P.obj.gt[c * HW + pix];
-      const bool with_depth = P.obj.w_depth != 0.f;
-      const float gdp = with_depth ? P.obj.gt_depth[pix] : 0.f;
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        const float r = m * (gain * im[c] + bias - gt[c]);
-        sc += fabsf(r);
-        const float g = kc * m * sgn(r);
-        ga += g * im[c];
-        gb += g;
-        P.obj.grad_image[c * HW + pix] = g * gain;
-      }
-      if (with_depth) {
-        const float dm = (P.obj.depth_mask_threshold < 0.f || gdp > P.obj.depth_mask_threshold) ? 1.f : 0.f;
-        const float r = dm * (C2D.y - gdp);
-        sd += fabsf(r);
-        if (P.obj.grad_depth) P.obj.grad_depth[pix] = kd * dm * sgn(r);
-      } else if (P.obj.grad_depth) {
-        P.obj.grad_depth[pix] = 0.f;
-      }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      sc += __shfl_down(sc, off); sd += __shfl_down(sd, off); ga += __shfl_down(ga, off); gb += __shfl_down(gb, off);
-    }
-    if (lane == 0) {
-      const size_t n = 4 * (size_t)P.T;
-      P.obj.partial[item] = sc;
-      P.obj.partial[n + item] = sd;
-      P.obj.partial[2 * n + item] = P.obj.apply_exposure ? ga * sgn(a) : 0.f;
-      P.obj.partial[3 * n + item] = P.obj.apply_exposure ? gb : 0.f;
     }
   }
 }
@@ -1238,10 +1188,8 @@ int launch_forward_blend(const KP& P, hipStream_t st) {
     launch("tile_sort", k_tile_sort_reg<false>, dim3(P.T), dim3(256), st, P);
     if (P.big_pass) launch("tile_sort_big", k_tile_sort<4096, 1024, false, 1024>, dim3(min(P.T, 512)), dim3(1024), st, P);
   }
-  const dim3 fgrid(grid_pad(4 * P.T, kFwdChunk));
-  if (P.obj.kind == 1) launch("blend_fwd", k_blend_fwd<1>, fgrid, dim3(64), st, P);
-  else if (P.obj.kind == 2) launch("blend_fwd", k_blend_fwd<2>, fgrid, dim3(64), st, P);
-  else launch("blend_fwd", k_blend_fwd<0>, fgrid, dim3(64), st, P);
+  if (P.obj.on) launch("blend_fwd", k_blend_fwd<true>, dim3(grid_pad(4 * P.T, kFwdChunk)), dim3(64), st, P);
+  else launch("blend_fwd", k_blend_fwd<false>, dim3(grid_pad(4 * P.T, kFwdChunk)), dim3(64), st, P);
   return check_launch();
 }
 

@@ -11,22 +11,17 @@ namespace mgs {
 
 // One struct carries everything a forward or backward kernel may need; it is passed
 // by value (kernarg segment -> SGPRs).
-// Objective evaluated in the forward blend's epilogue (native iterations only: mgs_tracking_iteration,
-// mgs_mapping_view_iteration).  The quadrant wave that has just finished a pixel holds its colour, depth and
-// opacity in registers; it forms the residual of tracking.hip's k_track_loss_onepass (kind 1) or
-// k_map_loss_fused (kind 2) there, writes d(loss)/d(image) [and d/d(depth)] for the backward and leaves its four
-// sums as ONE partial per quadrant wave - the loss launch between the forward and the backward is gone.
+// Tracking objective evaluated in the forward blend's epilogue (native first-order tracking iteration only:
+// mgs_tracking_iteration).  The quadrant wave that has just finished a pixel holds its colour and opacity in
+// registers; it forms the residual of tracking.hip's k_track_loss_onepass there, writes d(loss)/d(image) for the
+// backward and leaves its four sums as ONE partial per quadrant wave - the loss launch between the forward and
+// the backward is gone.
 struct KObj {
-  int kind;                                           // 0: none, 1: tracking (norm of the Hubered residual), 2: mapping (L1 colour + depth)
-  float exposure_eps, huber_delta;                    // huber_delta: tracking only
-  float w_rgb, w_depth, depth_mask_threshold;         // mapping only
-  int apply_exposure;                                 // mapping only (tracking always applies it)
+  int on;
+  float exposure_eps, huber_delta;
   const float *gt, *mask, *exposure_a, *exposure_b;   // gt [3][H*W]; mask [H*W] or null
-  const float* gt_depth;                              // mapping with w_depth != 0: [H*W]
   float* grad_image;                                  // [3][H*W]
-  float* grad_depth;                                  // mapping: [H*W] or null
-  float* partial;                                     // [4][4T], one entry per quadrant wave: tracking sum h^2 | d/da | d/db | sum |r|;
-                                                      // mapping sum |r_colour| | sum |r_depth| | d/da | d/db
+  float* partial;                                     // [4][4T]: sum h^2 | d/da | d/db | sum |r|, one entry per quadrant wave
 };
 
 struct KP {

@@ -54,32 +54,21 @@ __global__ __launch_bounds__(512) void k_pose_adam_update(mgs_pose_adam_args A) 
   // Many partials (the objective evaluated in the forward's epilogue leaves one per quadrant wave, 4T of them):
   // all 512 threads sum the four arrays together - every load of a thread independent, a wave sum, the eight
   // wave totals added in a fixed order by thread 0 below - instead of one wave walking each array.
-  // mode 1 (tracking): sum h^2 | d/da | d/db | sum |r|;  mode 0 (mapping): sum |r_colour| | sum |r_depth| | d/da | d/db
-  const bool coop = A.loss_partials && A.num_loss_partials > 1024 &&
-                    (!A.exposure_partials || A.num_exposure_partials == A.num_loss_partials) &&
-                    (A.loss_norm_mode == 1 ? (A.exposure_partials && (!A.l1_partials || A.num_l1_partials == A.num_loss_partials))
-                                           : true);
+  const bool coop = A.loss_partials && A.exposure_partials && A.loss_norm_mode == 1 && A.num_loss_partials > 1024 &&
+                    A.num_exposure_partials == A.num_loss_partials &&
+                    (!A.l1_partials || A.num_l1_partials == A.num_loss_partials);
   __shared__ float s_coop[4][8];
   if (coop) {
     const int n = A.num_loss_partials;
-    const float* q1 = A.loss_norm_mode == 1 ? A.exposure_partials : A.loss_partials + n;
-    const float* q2 = A.loss_norm_mode == 1 ? A.exposure_partials + n : A.exposure_partials;
-    const float* q3 = A.loss_norm_mode == 1 ? ((A.l1_partials && A.best) ? A.l1_partials : nullptr)
-                                            : (A.exposure_partials ? A.exposure_partials + n : nullptr);
-    // (an absent array is read from a present one and its sum dropped: the loads stay unconditional, so all of
-    // an unrolled trip's loads are in flight together)
-    const float* r2 = q2 ? q2 : A.loss_partials;
-    const float* r3 = q3 ? q3 : A.loss_partials;
+    const float* l1p = (A.l1_partials && A.best) ? A.l1_partials : nullptr;
     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
 #pragma unroll 5
     for (int i = threadIdx.x; i < n; i += 512) {
       v0 += A.loss_partials[i];
-      v1 += q1[i];
-      v2 += r2[i];
-      v3 += r3[i];
+      v1 += A.exposure_partials[i];
+      v2 += A.exposure_partials[n + i];
+      if (l1p) v3 += l1p[i];
     }
-    if (!q2) v2 = 0.f;
-    if (!q3) v3 = 0.f;
     for (int off = 32; off > 0; off >>= 1) {
       v0 += __shfl_down(v0, off); v1 += __shfl_down(v1, off); v2 += __shfl_down(v2, off); v3 += __shfl_down(v3, off);
     }
@@ -120,8 +109,7 @@ __global__ __launch_bounds__(512) void k_pose_adam_update(mgs_pose_adam_args A) 
 #pragma unroll
       for (int w = 0; w < 8; w++) t[c] += s_coop[c][w];
     }
-    if (A.loss_norm_mode == 1) { s_loss[0] = t[0]; s_g[6] = t[1]; s_g[7] = t[2]; s_l1 = t[3]; }
-    else { s_loss[0] = t[0]; s_loss[1] = t[1]; s_g[6] = t[2]; s_g[7] = t[3]; }
+    s_loss[0] = t[0]; s_g[6] = t[1]; s_g[7] = t[2]; s_l1 = t[3];
   }
   if (A.sticky_converged && A.converged && *A.converged != 0) return;    // the reference has left its loop
   float grad_scale = 1.f;
@@ -624,6 +612,8 @@ __global__ __launch_bounds__(kLossBlock) void k_map_loss_finish(mgs_mapping_loss
     A.loss[0] = A.w_rgb * tc / (3.f * hw) + A.w_depth * td / hw;
   }
 }
+
+__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
 
 __global__ __launch_bounds__(kLossBlock) void k_map_loss_bwd(mgs_mapping_loss_args A) {
   __shared__ float s_red[kLossBlock / 64];
