@@ -61,14 +61,18 @@ __global__ __launch_bounds__(512) void k_pose_adam_update(mgs_pose_adam_args A) 
   if (coop) {
     const int n = A.num_loss_partials;
     const float* l1p = (A.l1_partials && A.best) ? A.l1_partials : nullptr;
+    // (an absent array is read from a present one and its sum dropped: the loads stay unconditional, so all of
+    // an unrolled trip's loads are in flight together)
+    const float* r3 = l1p ? l1p : A.loss_partials;
     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
 #pragma unroll 5
     for (int i = threadIdx.x; i < n; i += 512) {
       v0 += A.loss_partials[i];
       v1 += A.exposure_partials[i];
       v2 += A.exposure_partials[n + i];
-      if (l1p) v3 += l1p[i];
+      v3 += r3[i];
     }
+    if (!l1p) v3 = 0.f;
     for (int off = 32; off > 0; off >>= 1) {
       v0 += __shfl_down(v0, off); v1 += __shfl_down(v1, off); v2 += __shfl_down(v2, off); v3 += __shfl_down(v3, off);
     }
