@@ -188,3 +188,37 @@ def test_full_size_forward_vectors_freeze_the_oracle():
     for k in ("image_sub", "depth_sub", "opacity_sub"):
         assert np.abs(gotc[k] - c[k]).max() <= 1e-6, k
     assert np.array_equal(gotc["radii_thin"], c["radii_thin"]) and np.array_equal(gotc["n_touched_thin"], c["n_touched_thin"])
+
+
+def test_sketch_problem_restatement_matches_the_reference():
+    """oracle/sketch_problem.py against what the REFERENCE's tests/sketch_utils.py returned on the same
+    seeds (tests/golden/sketch_bound.npz, made by make_sketch_bound.py): the problem generator, the
+    CountSketch matrix, the distortion and the two bounds run_test asserts (sketch_utils.py:58-124)."""
+    from scipy.linalg import lstsq
+    from oracle import sketch_problem as SP
+    G = np.load(os.path.join(GOLD, "sketch_bound.npz"))
+    n, noise, lam, x_norm, smax, smin = G["params"]
+    assert (int(n), lam) == (SP.REFERENCE_TEST["n"], SP.REFERENCE_TEST["lambda_"])
+    for tag in ("small", "large"):
+        m, seed = int(G[f"{tag}_m"]), int(G[f"{tag}_seed"])
+        A, b, x = SP.gen_problem(m, int(n), smax, smin, lam, noise, x_norm, seed=seed)
+        if tag == "small":
+            assert np.allclose(A, G["small_A"], rtol=1e-5, atol=1e-9) and np.allclose(b, G["small_b"], rtol=1e-5, atol=1e-9)
+        else:
+            assert np.allclose(A[::64], G["large_A_rows64"], rtol=1e-5, atol=1e-9)
+            assert np.allclose(b[::64], G["large_b_rows64"], rtol=1e-5, atol=1e-9)
+        assert np.allclose(A.T @ A, G[f"{tag}_AtA"], rtol=1e-9, atol=1e-12)
+        assert np.allclose(A.T @ b, G[f"{tag}_Atb"], rtol=1e-9, atol=1e-12)
+        assert np.allclose(x, G[f"{tag}_x"], rtol=1e-12)
+        # the reference's own (unsigned, with-replacement) sketch: same solution, distortion and bounds
+        S = SP.count_sketch(G[f"{tag}_ref_bucket"].astype(np.int64), 32)
+        SA, Sb = S @ A, S @ b
+        At, bt = SP.damped(SA, Sb, lam)
+        x_sketch = lstsq(At, bt)[0]
+        assert np.allclose(x_sketch, G[f"{tag}_ref_x_sketch"], rtol=1e-7, atol=1e-13)
+        x_opt, ub, ub_hat, st = SP.bounds(A, b, lam, SA, Sb, x_sketch, 32)
+        assert np.allclose(x_opt, G[f"{tag}_x_opt"], rtol=1e-8, atol=1e-14)
+        assert abs(st["res"] - float(G[f"{tag}_res"])) < 1e-10 and abs(st["sigma_min"] - float(G[f"{tag}_sigma_min"])) < 1e-9
+        assert abs(st["distortion"] - float(G[f"{tag}_ref_distortion"])) < 1e-9
+        assert np.allclose([ub, ub_hat], G[f"{tag}_ref_bounds"], rtol=1e-6)
+        assert np.linalg.norm(x_opt - x_sketch) < min(ub, ub_hat)
