@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MGS_ABI_VERSION 6
+#define MGS_ABI_VERSION 7
 
 typedef enum mgs_status {
   MGS_OK = 0,
@@ -288,11 +288,16 @@ typedef struct mgs_pose_adam_args {
    * loss_tracking_scalar = ||loss_tracking_img||_1) of the render this iteration started from;
    * when their sum is below best[0] the state that was rendered (T, exposure_a, exposure_b BEFORE
    * this step - what TempCamera(viewpoint) copies) is stored: best = float[MGS_TRACK_BEST_FLOATS]
-   * {best L1 (caller sets +inf), T[16], a, b, index of the best iteration, iteration counter}. */
+   * {best L1 (caller sets +inf), T[16], a, b, index of the best iteration, iteration counter,
+   *  [21] the criterion (L1) of the LAST iteration's render, [22] |step| of the last iteration (|tau| applied by
+   *  update_pose, or |x| of the LM solve) - a per-iteration trace for tests and logging, [23] spare}. */
   const float* l1_partials;
   float* best;
   int32_t num_l1_partials;
-  int32_t reserved0;
+  /* loss_norm_mode == 1: the objective is the p-norm (sum |h|^p)^(1/p) of utils/slam_frontend.py:596-600
+   * (p = 2 with Huber, RGN.pnorm without; configs/mono/tum/base_config.yaml:249); loss_partials are block
+   * sums of |h|^p, loss = sum^(1/p) and the gradients are scaled by loss^(1-p).  <= 0 means 2. */
+  float loss_pnorm;
 } mgs_pose_adam_args;
 #define MGS_TRACK_BEST_FLOATS 24
 
@@ -362,7 +367,11 @@ typedef struct mgs_lm_step_args {
   float increase_factor, decrease_factor, min_lambda, max_lambda;
   float converged_threshold; /* lm_state[3] = |x| < threshold (slam_frontend.py:699) */
   /* With lm_state: a converged step is NOT applied and every later call is a no-op (the reference
-   * breaks before new_viewpoint_params is ever assigned, slam_frontend.py:699-706).
+   * assigns new_viewpoint_params at slam_frontend.py:690-691 but only APPLIES it at the top of the next
+   * iteration, :474-479, and the `break` of :699-706 comes first).  A non-converged step is applied at once
+   * here: equal to the reference for every iteration but the LAST of a frame, whose step the reference
+   * never applies - a caller that ends a frame on the last rendered state (use_best_loss off) restores it
+   * (NativeTracker.run does).
    * best (or NULL): same float[MGS_TRACK_BEST_FLOATS] block as mgs_pose_adam_args.best; *loss is the
    * criterion, the pose / exposure this iteration rendered (before the step) is what is stored. */
   int32_t reserved0;
@@ -384,7 +393,7 @@ int32_t mgs_lm_solve_step(const mgs_lm_step_args* args, void* stream);
 
 /* Monocular tracking objective (utils/slam_utils.py:188-205, :58-75; norm at
  * utils/slam_frontend.py:596-598):
- *   loss = || Huber_delta( opacity * mask * ((|a| + eps) * image + b - gt) ) ||_2
+ *   loss = || Huber_delta( opacity * mask * ((|a| + eps) * image + b - gt) ) ||_p   (p = pnorm, below)
  * huber_delta <= 0 disables Huber.  `partial` holds mgs_tracking_loss_partial_count floats
  * (four per reduction block: forward sums, the two exposure-gradient sums, and - onepass only -
  * the block sums of |residual| before Huber),
@@ -406,6 +415,13 @@ typedef struct mgs_tracking_loss_args {
   float* grad_image;           /* [3,H,W] */
   float* grad_a;               /* [1] */
   float* grad_b;               /* [1] */
+  /* p of the norm, utils/slam_frontend.py:596-600: the reference uses p = 2 when use_huber is on and
+   * RGN.pnorm (configs/mono/tum/base_config.yaml:249: 1) when it is off.  <= 0 means 2 (a zero-initialised
+   * block keeps the Hubered L2 objective).  p = 1 and p = 2 are closed forms; any other p >= 1 goes
+   * through powf.  `partial` then holds block sums of |h|^p, scalars[0] = loss = (sum)^(1/p) and
+   * scalars[1] = loss^(1-p), the factor of the norm's derivative. */
+  float pnorm;
+  int32_t reserved0;
 } mgs_tracking_loss_args;
 
 int32_t mgs_tracking_loss_partial_count(int64_t num_pixels);
@@ -520,13 +536,18 @@ int32_t mgs_sketch_residual(const mgs_sketch_residual_args* args, void* stream);
  * consumes the sketched Jacobian alone) -> mgs_lm_solve_step with the device-resident
  * trust-region state.
  * `base` as for mgs_tracking_iteration (its adam block is unused except T / exposure);
- * `accum` holds stack*sketch*9 + 4 floats: Sf[d] | sj_exposure[d,2] | sj_tau[d,6] | l1, pad. */
+ * `accum` holds repeat*stack*sketch*9 + 4 floats: Sf[R d] | sj_exposure[R d,2] | sj_tau[R d,6] | l1, pad.
+ * repeat_dim (RGN.second_order.repeat_dim, configs/mono/tum/base_config.yaml:258; utils/slam_frontend.py:654-669):
+ * R backward passes over ONE render, each with its own partition (key + r * golden ratio) and weights; the rows of
+ * Sf / SJ are stacked ([R d] rows in the solve).  `bucket` / `weights` then hold R planes of H*W.
+ * If a step of the sequence fails after the accumulators were touched, they (and the per-pixel Jacobian rows in
+ * sketch_ws) are cleared before the error is returned, so scratch_kept_zero survives a failed call. */
 typedef struct mgs_tracking_so_args {
   mgs_tracking_iter_args base;
   int32_t stack_dim, sketch_dim;
   uint64_t key;              /* changes every iteration */
-  int32_t* bucket;           /* [H*W] scratch */
-  float* weights;            /* [H*W] scratch */
+  int32_t* bucket;           /* [repeat, H*W] scratch */
+  float* weights;            /* [repeat, H*W] scratch */
   float* accum;
   void* sketch_ws;           /* sketch_bytes of backward scratch */
   mgs_lm_step_args lm;       /* SJ / Sf / sj_* / loss fields are filled in by the call */
@@ -534,7 +555,7 @@ typedef struct mgs_tracking_so_args {
    * iteration's own kernels restore the zeros they need (the LM kernel: accum; the bucket kernel: the
    * per-pixel Jacobian rows), so no hipMemsetAsync is enqueued per iteration */
   int32_t scratch_kept_zero;
-  int32_t reserved0;
+  int32_t repeat_dim;        /* >= 1; 0 means 1 */
 } mgs_tracking_so_args;
 
 int32_t mgs_tracking_iteration_second_order(const mgs_tracking_so_args* args, void* stream);

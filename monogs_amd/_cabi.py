@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MGS_LIB_PATH: load another build of the SAME library (kernel experiments, the -DMGS_STAMP build)
 LIB_PATH = os.environ.get("MGS_LIB_PATH") or os.path.join(_HERE, "lib", "libmonogs_raster.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 EXPORTS = (
     "mgs_abi_version", "mgs_struct_size", "mgs_status_string", "mgs_raster_workspace_query",
@@ -83,10 +83,11 @@ class PoseAdamArgs(C.Structure):
            ("num_loss_partials", C.c_int32), ("loss_w_rgb", C.c_float), ("loss_w_depth", C.c_float),
            ("loss_view", _fp), ("loss_accum", _fp), ("loss_grad_out", _fp),
            ("loss_norm_mode", C.c_int32), ("sticky_converged", C.c_int32), ("l1_partials", _fp),
-           ("best", _fp), ("num_l1_partials", C.c_int32), ("reserved0", C.c_int32)])
+           ("best", _fp), ("num_l1_partials", C.c_int32), ("loss_pnorm", C.c_float)])
 
 
-TRACK_BEST_FLOATS = 24     # MGS_TRACK_BEST_FLOATS: {best L1, T[16], a, b, index of the best iteration, counter}
+TRACK_BEST_FLOATS = 24     # MGS_TRACK_BEST_FLOATS: {best L1, T[16], a, b, index of the best iteration, counter,
+                           #  L1 of the last iteration's render, |step| of the last iteration, spare}
 
 
 class MappingLossArgs(C.Structure):
@@ -112,7 +113,8 @@ class LMStepArgs(C.Structure):
 class TrackingLossArgs(C.Structure):
     _fields_ = ([(n, _fp) for n in ("image", "opacity", "gt", "mask", "exposure_a", "exposure_b")]
                 + [("exposure_eps", C.c_float), ("huber_delta", C.c_float), ("num_pixels", C.c_int64)]
-                + [(n, _fp) for n in ("partial", "scalars", "grad_out", "grad_image", "grad_a", "grad_b")])
+                + [(n, _fp) for n in ("partial", "scalars", "grad_out", "grad_image", "grad_a", "grad_b")]
+                + [("pnorm", C.c_float), ("reserved0", C.c_int32)])
 
 
 class TrackingIterArgs(C.Structure):
@@ -133,7 +135,7 @@ class SketchResidualArgs(C.Structure):
 class TrackingSOArgs(C.Structure):
     _fields_ = [("base", TrackingIterArgs), ("stack_dim", C.c_int32), ("sketch_dim", C.c_int32),
                 ("key", C.c_uint64), ("bucket", _fp), ("weights", _fp), ("accum", _fp),
-                ("sketch_ws", _fp), ("lm", LMStepArgs), ("scratch_kept_zero", C.c_int32), ("reserved0", C.c_int32)]
+                ("sketch_ws", _fp), ("lm", LMStepArgs), ("scratch_kept_zero", C.c_int32), ("repeat_dim", C.c_int32)]
 
 
 ADAM_MAX_GROUPS = 8

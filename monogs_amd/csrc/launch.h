@@ -1,6 +1,7 @@
 // Kernel launch helper with optional per-kernel hipEvent timing (mgs_profile_*).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdio>
 
 namespace mgs {
@@ -26,10 +27,27 @@ inline bool launches_ok() {
   return ok;
 }
 
+// An error another HIP user of this thread (PyTorch, RCCL) left pending is not ours to return - but it is not
+// ours to swallow silently either: hipGetLastError() clears it, so it is named on stderr (the first few times).
+inline void drain_foreign_error() {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return;
+  static std::atomic<int> said{0};
+  if (said.fetch_add(1) < 4)
+    fprintf(stderr, "monogs_raster: a HIP error was already pending on this thread before a launch of ours "
+                    "(left by another HIP user, cleared here): %s\n", hipGetErrorString(e));
+}
+
+// hipMemsetAsync / hipMemcpyAsync of the entry points go through the same per-thread slot and message
+inline bool hip_ok(const char* what, hipError_t e) {
+  note_launch(what, e);
+  return e == hipSuccess;
+}
+
 template <typename K, typename... A>
 inline void launch_smem(const char* name, K kernel, dim3 grid, dim3 block, size_t smem,
                         hipStream_t st, A... args) {
-  (void)hipGetLastError();        // whatever is pending on this thread is not ours
+  drain_foreign_error();
   if (profile_on()) {
     hipEvent_t a, b;
     (void)hipEventCreate(&a);

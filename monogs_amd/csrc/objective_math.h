@@ -15,4 +15,27 @@ __device__ __forceinline__ float huber(float x, float delta, float& dh) {
   return copysignf(s, x);
 }
 
+// The p-norm objective (sum |h|^p)^(1/p) of utils/slam_frontend.py:596-600 (p = 2 with Huber, RGN.pnorm
+// without).  Per sample: phi = |h|^p (what is summed) and gam = |h|^(p-1) sign(h); with S = sum phi the value is
+// loss = S^(1/p) and d loss / d h = loss^(1-p) gam - the scalar factor is applied by the consumer of the sums
+// (norm_finish), everything in between being linear in it.  p = 2: (h^2, h), the form of rounds 1-3.
+// p = 1: (|h|, sign h), sign(0) = 0 as torch.norm's derivative has it.
+__device__ __forceinline__ float norm_p(float pnorm) { return pnorm > 0.f ? pnorm : 2.f; }
+
+__device__ __forceinline__ void norm_terms(float h, float p, float& phi, float& gam) {
+  if (p == 2.f) { phi = h * h; gam = h; return; }
+  const float ah = fabsf(h);
+  if (p == 1.f) { phi = ah; gam = h > 0.f ? 1.f : (h < 0.f ? -1.f : 0.f); return; }
+  const float q = ah > 0.f ? powf(ah, p - 1.f) : 0.f;
+  phi = q * ah; gam = copysignf(q, h);
+}
+
+// loss = S^(1/p) and scale = loss^(1-p) (0 when the loss is 0: torch.norm's derivative at the origin)
+__device__ __forceinline__ void norm_finish(float S, float p, float& loss, float& scale) {
+  if (p == 2.f) { loss = sqrtf(S); scale = loss > 0.f ? 1.f / loss : 0.f; return; }
+  if (p == 1.f) { loss = S; scale = 1.f; return; }
+  loss = S > 0.f ? powf(S, 1.f / p) : 0.f;
+  scale = loss > 0.f ? powf(loss, 1.f - p) : 0.f;
+}
+
 }  // namespace mgs

@@ -718,25 +718,29 @@ __global__ __launch_bounds__(kPreBlock) void k_preprocess_bwd(KP P, KB B) {
         }
 #pragma unroll
         for (int c = 0; c < 3; c++) put(&M.g_fdc[3 * (size_t)idx + c], d3[c]);
-        if (M.g_frest)      // stored degree above the active one: the higher bands get no gradient
-          for (int k = 3; k < 3 * P.K; k++) put(&M.g_frest[(size_t)3 * (P.K - 1) * idx + (k - 3)], 0.f);
+        if (M.g_frest && !add)      // stored degree above the active one: the higher bands get no gradient
+          for (int k = 3; k < 3 * P.K; k++) M.g_frest[(size_t)3 * (P.K - 1) * idx + (k - 3)] = 0.f;
       } else {
-        float dsh[48];
+        // the coefficient gradients go to memory as they are produced (no 48-entry array: it lived in scratch
+        // memory, 208 B per lane, and held this instantiation at 4 waves per SIMD)
+        float* frest = M.g_frest ? M.g_frest + (size_t)3 * (P.K - 1) * idx : nullptr;
+        auto sink = [&](int k, float v) {
+          if (k < 3) put(&M.g_fdc[3 * (size_t)idx + k], v);
+          else if (frest) put(&frest[k - 3], v);
+        };
+        int active = 0;       // coefficient floats that received a gradient
         if (radius > 0 && P.shs) {
           if (P.deg == 0) {
 #pragma unroll
-            for (int c = 0; c < 3; c++) dsh[c] = (flags & (1u << c)) ? 0.f : SH_C0 * grgb[c];
-            for (int k = 3; k < 3 * P.K; k++) dsh[k] = 0.f;
+            for (int c = 0; c < 3; c++) sink(c, (flags & (1u << c)) ? 0.f : SH_C0 * grgb[c]);
+            active = 3;
           } else {
-            sh_backward(P.deg, P.K, P.shs + (size_t)3 * P.K * idx, p, P.campos, flags, grgb, dsh, dmean);
+            sh_backward_emit(P.deg, P.shs + (size_t)3 * P.K * idx, p, P.campos, flags, grgb, dmean, sink);
+            active = 3 * (P.deg + 1) * (P.deg + 1);
           }
-        } else {
-          for (int k = 0; k < 3 * P.K; k++) dsh[k] = 0.f;
         }
-#pragma unroll
-        for (int c = 0; c < 3; c++) put(&M.g_fdc[3 * (size_t)idx + c], dsh[c]);
-        if (M.g_frest)
-          for (int k = 3; k < 3 * P.K; k++) put(&M.g_frest[(size_t)3 * (P.K - 1) * idx + (k - 3)], dsh[k]);
+        if (!add)             // overwrite mode: everything that got no gradient is zero (accumulating: unchanged)
+          for (int k = active; k < 3 * P.K; k++) sink(k, 0.f);
       }
 #pragma unroll
       for (int i = 0; i < 3; i++) put(&M.g_xyz[3 * (size_t)idx + i], dmean[i]);
@@ -867,9 +871,11 @@ int launch_backward(const KP& P, const KB& B, hipStream_t st, bool skip_tau_redu
     const size_t nacc = (size_t)B.stack_dim * B.sketch_dim * 6;
     if (nacc * sizeof(float) > 64 * 1024) return MGS_ERR_UNSUPPORTED;
     if (!B.scratch_kept_zero &&
-        (hipMemsetAsync(B.pix_jac, 0, HW * 6 * sizeof(float), st) != hipSuccess ||
-         hipMemsetAsync(B.g_sketch, 0, nacc * sizeof(float), st) != hipSuccess))
+        (!hip_ok("memset(per-pixel Jacobian rows)", hipMemsetAsync(B.pix_jac, 0, HW * 6 * sizeof(float), st)) ||
+         !hip_ok("memset(sketched Jacobian)", hipMemsetAsync(B.g_sketch, 0, nacc * sizeof(float), st)))) {
+      launches_ok();      // (reported above; the per-thread slot is cleared for the next entry point)
       return MGS_ERR_LAUNCH;
+    }
     launch("sketch_prep", k_sketch_prep, dim3((P.N + kPreBlock - 1) / kPreBlock), dim3(kPreBlock), st, P, B);
     if (B.sketch_only)
       launch("blend_bwd_sketch", k_blend_bwd<true, true>, dim3(grid_pad((P.max_segs + kSketchReps - 1) / kSketchReps, kBwdChunk)), dim3(64), st, P, B);

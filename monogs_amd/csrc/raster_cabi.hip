@@ -268,13 +268,26 @@ int32_t mgs_tracking_iteration(const mgs_tracking_iter_args* args, void* stream)
   if ((rc = fill_kp(args->fwd, true, true, P)) != MGS_OK) return rc;
   const Layout lay = make_layout(args->fwd.shape);
   float* obj_partial = reinterpret_cast<float*>(static_cast<char*>(args->fwd.geom) + lay.obj_partial);
-  P.obj.on = 1;
-  P.obj.exposure_eps = L.exposure_eps; P.obj.huber_delta = L.huber_delta;
-  P.obj.gt = L.gt; P.obj.mask = L.mask; P.obj.exposure_a = L.exposure_a; P.obj.exposure_b = L.exposure_b;
-  P.obj.grad_image = args->grad_image; P.obj.partial = obj_partial;
-  if ((rc = launch_forward_blend(P, (hipStream_t)stream)) != MGS_OK) return rc;
-  L.partial = obj_partial;
-  const int32_t nblk = 4 * P.T;
+  if (L.pnorm > 0.f && L.pnorm < 1.f) return MGS_ERR_BAD_ARGUMENT;
+  const float pn = L.pnorm > 0.f ? L.pnorm : 2.f;
+  int32_t nblk = 4 * P.T;
+  if (pn == 1.f || pn == 2.f) {
+    P.obj.on = 1;
+    P.obj.p1 = pn == 1.f;
+    P.obj.exposure_eps = L.exposure_eps; P.obj.huber_delta = L.huber_delta;
+    P.obj.gt = L.gt; P.obj.mask = L.mask; P.obj.exposure_a = L.exposure_a; P.obj.exposure_b = L.exposure_b;
+    P.obj.grad_image = args->grad_image; P.obj.partial = obj_partial;
+    if ((rc = launch_forward_blend(P, (hipStream_t)stream)) != MGS_OK) return rc;
+    L.partial = obj_partial;
+  } else {
+    // any other p >= 1 (powf per sample): the plain forward blend, then the one-pass loss kernel
+    // (needs loss.partial: mgs_tracking_loss_partial_count floats)
+    if (!L.partial) return MGS_ERR_BAD_ARGUMENT;
+    if ((rc = launch_forward_blend(P, (hipStream_t)stream)) != MGS_OK) return rc;
+    L.image = args->fwd.out_color; L.opacity = args->fwd.out_opacity; L.grad_image = args->grad_image;
+    L.num_pixels = (int64_t)P.W * P.H;
+    if ((rc = mgs_tracking_loss_onepass(&L, &nblk, stream)) != MGS_OK) return rc;
+  }
   mgs_backward_args B;
   memset(&B, 0, sizeof(B));
   B.fwd = args->fwd;
@@ -289,7 +302,7 @@ int32_t mgs_tracking_iteration(const mgs_tracking_iter_args* args, void* stream)
   A.tau_partials = tau_partials; A.num_tau_partials = npre;
   A.exposure_partials = L.partial + nblk; A.num_exposure_partials = nblk;
   A.loss_partials = L.partial; A.num_loss_partials = nblk;
-  A.loss_norm_mode = 1; A.loss_grad_out = args->one;
+  A.loss_norm_mode = 1; A.loss_grad_out = args->one; A.loss_pnorm = pn;
   A.loss_view = L.scalars; A.loss_accum = nullptr;
   A.best = args->best; A.l1_partials = L.partial + 3 * (size_t)nblk; A.num_l1_partials = nblk;
   A.projection = args->fwd.projmatrix_raw;
@@ -358,14 +371,18 @@ int32_t mgs_tracking_iteration_second_order(const mgs_tracking_so_args* args, vo
   const mgs_tracking_iter_args& b = args->base;
   if (!b.bwd || !b.grad_image || !b.grad_tau || !b.adam.T || !b.fwd.viewmatrix || !b.fwd.projmatrix ||
       b.fwd.shape.pair_capacity < 1 || !args->bucket || !args->weights || !args->accum || !args->sketch_ws ||
-      !args->lm.lm_state || !args->lm.x_out || args->stack_dim < 1 || args->sketch_dim < 1)
+      !args->lm.lm_state || !args->lm.x_out || args->stack_dim < 1 || args->sketch_dim < 1 || args->repeat_dim < 0)
     return MGS_ERR_BAD_ARGUMENT;
   const int64_t HW = (int64_t)b.fwd.shape.width * b.fwd.shape.height;
   const int d = args->stack_dim * args->sketch_dim;
+  const int R = args->repeat_dim > 0 ? args->repeat_dim : 1;
+  const size_t rows = (size_t)R * d;
+  // accum: Sf[R d] | sj_exposure[R d, 2] | sj_tau[R d, 6] | l1, l1 of the later repeats (dropped), pad
   float* Sf = args->accum;
-  float* sj_exp = Sf + d;
-  float* sj_tau = sj_exp + 2 * (size_t)d;
-  float* l1 = sj_tau + 6 * (size_t)d;
+  float* sj_exp = Sf + rows;
+  float* sj_tau = sj_exp + 2 * rows;
+  float* l1 = sj_tau + 6 * rows;
+  hipStream_t st = (hipStream_t)stream;
   int32_t rc = MGS_OK;
   if (!b.camera_matrices_valid) {
     rc = mgs_camera_from_pose(b.adam.T, b.fwd.projmatrix_raw, const_cast<float*>(b.fwd.viewmatrix),
@@ -378,36 +395,57 @@ int32_t mgs_tracking_iteration_second_order(const mgs_tracking_so_args* args, vo
   // scratch_kept_zero the caller guarantees zeros on the first call and the LM kernel / the bucket kernel -
   // the consumers - restore them: four hipMemsetAsync launches (~5 us each) less per iteration.
   const bool kept = args->scratch_kept_zero != 0;
-  if (!kept && (hipMemsetAsync(Sf, 0, sizeof(float) * 3 * (size_t)d, (hipStream_t)stream) != hipSuccess ||
-                hipMemsetAsync(l1, 0, sizeof(float) * 4, (hipStream_t)stream) != hipSuccess))
+  if (!kept && (!hip_ok("memset(sketch accumulators)", hipMemsetAsync(Sf, 0, sizeof(float) * 3 * rows, st)) ||
+                !hip_ok("memset(sketch l1)", hipMemsetAsync(l1, 0, sizeof(float) * 4, st)))) {
+    launches_ok();
     return MGS_ERR_LAUNCH;
-  mgs_sketch_residual_args R;
-  memset(&R, 0, sizeof(R));
-  R.image = b.fwd.out_color; R.opacity = b.fwd.out_opacity; R.gt = b.loss.gt; R.mask = b.loss.mask;
-  R.exposure_a = b.loss.exposure_a; R.exposure_b = b.loss.exposure_b;
-  R.exposure_eps = b.loss.exposure_eps; R.huber_delta = b.loss.huber_delta; R.num_pixels = HW;
-  R.stack_dim = args->stack_dim; R.sketch_dim = args->sketch_dim;
-  R.bucket = args->bucket; R.weights = args->weights; R.grad_image = b.grad_image;
-  R.Sf = Sf; R.sj_exposure = sj_exp; R.l1 = l1;
-  R.assign = 1; R.assign_key = args->key;     // the bucket partition is drawn inside the residual pass
-  if ((rc = mgs_sketch_residual(&R, stream)) != MGS_OK) return rc;
-  mgs_backward_args B;
-  memset(&B, 0, sizeof(B));
-  B.fwd = b.fwd; B.grad_color = b.grad_image; B.bwd = b.bwd; B.grad_tau = b.grad_tau;
-  B.sketch_mode = 1; B.sketch_dim = args->sketch_dim; B.stack_dim = args->stack_dim;
-  B.sketch_bucket_flat = args->bucket; B.grad_sketch_dtau = sj_tau; B.sketch_ws = args->sketch_ws;
-  // only grad_sketch_dtau is consumed by the LM step: J-only backward (no per-splat sums,
-  // no preprocess backward, no grad_tau)
-  if ((rc = raster_backward_impl(&B, stream, true, nullptr, nullptr, true, kept)) != MGS_OK) return rc;
+  }
+  // From here on the accumulators may hold partial sums.  In kept-zero mode only the LAST kernels of the sequence
+  // restore the zeros, so a failure in between (bad argument, unsupported size, a failed launch) must not leave
+  // them dirty for the next call: clear them - and the per-pixel Jacobian rows - before returning the error.
+  const Layout lay = make_layout(b.fwd.shape);
+  auto fail = [&](int32_t code) {
+    if (kept) {
+      (void)hipMemsetAsync(args->accum, 0, sizeof(float) * (9 * rows + 4), st);
+      (void)hipMemsetAsync(static_cast<char*>(args->sketch_ws) + lay.pix_jac, 0, sizeof(float) * 6 * (size_t)HW, st);
+    }
+    return code;
+  };
+  // `repeat_dim` backward passes over ONE render (utils/slam_frontend.py:654-669): repeat r draws its own
+  // partition and weights, sums its residual buckets into Sf[r] and harvests SJ[r]; the rows are stacked.
+  for (int r = 0; r < R; r++) {
+    mgs_sketch_residual_args Rr;
+    memset(&Rr, 0, sizeof(Rr));
+    Rr.image = b.fwd.out_color; Rr.opacity = b.fwd.out_opacity; Rr.gt = b.loss.gt; Rr.mask = b.loss.mask;
+    Rr.exposure_a = b.loss.exposure_a; Rr.exposure_b = b.loss.exposure_b;
+    Rr.exposure_eps = b.loss.exposure_eps; Rr.huber_delta = b.loss.huber_delta; Rr.num_pixels = HW;
+    Rr.stack_dim = args->stack_dim; Rr.sketch_dim = args->sketch_dim;
+    Rr.bucket = args->bucket + (size_t)r * HW; Rr.weights = args->weights + (size_t)r * HW; Rr.grad_image = b.grad_image;
+    Rr.Sf = Sf + (size_t)r * d; Rr.sj_exposure = sj_exp + 2 * (size_t)r * d;
+    Rr.l1 = r == 0 ? l1 : l1 + 1;               // the L1 criterion is the render's: counted once
+    Rr.assign = 1;                              // the bucket partition is drawn inside the residual pass
+    Rr.assign_key = args->key + 0x9E3779B97F4A7C15ull * (uint64_t)r;
+    if ((rc = mgs_sketch_residual(&Rr, stream)) != MGS_OK) return fail(rc);
+    mgs_backward_args B;
+    memset(&B, 0, sizeof(B));
+    B.fwd = b.fwd; B.grad_color = b.grad_image; B.bwd = b.bwd; B.grad_tau = b.grad_tau;
+    B.sketch_mode = 1; B.sketch_dim = args->sketch_dim; B.stack_dim = args->stack_dim;
+    B.sketch_bucket_flat = args->bucket + (size_t)r * HW; B.grad_sketch_dtau = sj_tau + 6 * (size_t)r * d;
+    B.sketch_ws = args->sketch_ws;
+    // only grad_sketch_dtau is consumed by the LM step: J-only backward (no per-splat sums,
+    // no preprocess backward, no grad_tau)
+    if ((rc = raster_backward_impl(&B, stream, true, nullptr, nullptr, true, kept)) != MGS_OK) return fail(rc);
+  }
   mgs_lm_step_args L = args->lm;
-  L.SJ = nullptr; L.sj_tau = sj_tau; L.sj_exposure = sj_exp; L.Sf = Sf; L.rows = d; L.loss = l1;
+  L.SJ = nullptr; L.sj_tau = sj_tau; L.sj_exposure = sj_exp; L.Sf = Sf; L.rows = (int32_t)rows; L.loss = l1;
   L.T = b.adam.T; L.exposure_a = b.adam.exposure_a; L.exposure_b = b.adam.exposure_b;
   L.best = b.best;
-  if (kept) { L.zero_after = args->accum; L.zero_count = 9 * d + 4; }
+  if (kept) { L.zero_after = args->accum; L.zero_count = (int32_t)(9 * rows + 4); }
   L.projection = b.fwd.projmatrix_raw;
   L.viewmatrix_out = const_cast<float*>(b.fwd.viewmatrix);
   L.projmatrix_out = const_cast<float*>(b.fwd.projmatrix);
-  return mgs_lm_solve_step(&L, stream);
+  if ((rc = mgs_lm_solve_step(&L, stream)) != MGS_OK) return fail(rc);
+  return MGS_OK;
 }
 
 int32_t mgs_profile_enable(int32_t on) {

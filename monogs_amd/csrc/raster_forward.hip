@@ -1064,9 +1064,9 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
     P.out_opacity[pix] = 1.f - T;
   }
   if constexpr (OBJ) {
-    // Tracking objective || Huber(opacity * mask * ((|a| + eps) * image + b - gt)) ||_2, one pixel per lane:
+    // Tracking objective || Huber(opacity * mask * ((|a| + eps) * image + b - gt)) ||_p (p = 2 or 1), one pixel per lane:
     // the per-sample arithmetic of k_track_loss_onepass (tracking.hip), channel by channel; d(loss)/d(image)
-    // WITHOUT the 1 / loss of the norm (k_pose_adam_update applies it to the pose gradient, which is linear in
+    // WITHOUT the loss^(1-p) of the norm (k_pose_adam_update applies it to the pose gradient, which is linear in
     // it).  The wave's four sums become partial entry `item` (= 4 tile + quadrant).
     float acc = 0.f, ga = 0.f, gb = 0.f, l1 = 0.f;
     const float a = P.obj.exposure_a[0];
@@ -1085,8 +1085,10 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
         const float r = om * (gain * im[c] + bias - gt[c]);
         l1 += fabsf(r);
         const float h = huber(r, P.obj.huber_delta, dh);
-        acc += h * h;
-        const float gr = h * dh * om;
+        float phi, gam;
+        norm_terms(h, P.obj.p1 ? 1.f : 2.f, phi, gam);
+        acc += phi;
+        const float gr = gam * dh * om;
         ga += gr * im[c];
         gb += gr;
         P.obj.grad_image[c * HW + pix] = gr * gain;
@@ -1173,9 +1175,11 @@ int launch_forward_blend(const KP& P, hipStream_t st) {
     else
       launch_smem("bin_emit", k_bin_lds<1024>, dim3(nblk), dim3(1024), sizeof(int) * (size_t)P.T, st, P, 1, per, 0);
   } else {
-    if (hipMemsetAsync(P.tile_cursor, 0, sizeof(int) * (size_t)P.T, st) != hipSuccess ||
-        hipMemsetAsync(P.n_touched, 0, sizeof(int) * (size_t)P.N, st) != hipSuccess)
+    if (!hip_ok("memset(tile cursors)", hipMemsetAsync(P.tile_cursor, 0, sizeof(int) * (size_t)P.T, st)) ||
+        !hip_ok("memset(n_touched)", hipMemsetAsync(P.n_touched, 0, sizeof(int) * (size_t)P.N, st))) {
+      launches_ok();
       return MGS_ERR_LAUNCH;
+    }
     launch("bin_emit", k_bin, dim3((P.N + 255) / 256), dim3(256), st, P, 1);
   }
   // crowded tiles are rare: for them a small grid walks the tile list instead of T mostly idle workgroups

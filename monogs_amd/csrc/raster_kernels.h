@@ -18,10 +18,11 @@ namespace mgs {
 // the backward is gone.
 struct KObj {
   int on;
+  int p1;                                             // 1: the norm is p = 1 (else p = 2; any other p takes the loss kernel)
   float exposure_eps, huber_delta;
   const float *gt, *mask, *exposure_a, *exposure_b;   // gt [3][H*W]; mask [H*W] or null
   float* grad_image;                                  // [3][H*W]
-  float* partial;                                     // [4][4T]: sum h^2 | d/da | d/db | sum |r|, one entry per quadrant wave
+  float* partial;                                     // [4][4T]: sum |h|^p | d/da | d/db | sum |r|, one entry per quadrant wave
 };
 
 struct KP {

@@ -317,8 +317,13 @@ struct GaussGrad {
   float dtau[6];
 };
 
-MGS_HD void sh_backward(int deg, int K, const float* sh, const float p[3], const float campos[3],
-                        uint32_t flags, const float g_rgb_in[3], float* dsh, float dmean[3]) {
+// Gradient of the SH colour w.r.t. the coefficients and (through the view direction) the mean.  Every
+// coefficient gradient of the ACTIVE bands (k < 3 (deg+1)^2) is handed to `emit(k, value)` exactly once, with a
+// literal k - a sink that stores straight to memory keeps no coefficient array alive (k_preprocess_bwd's mapping
+// mode held a 48-entry array in scratch memory until round 4); bands above the active degree are the caller's.
+template <typename Emit>
+MGS_HD void sh_backward_emit(int deg, const float* sh, const float p[3], const float campos[3], uint32_t flags,
+                             const float g_rgb_in[3], float dmean[3], Emit&& emit) {
   float g[3];
   for (int c = 0; c < 3; c++) g[c] = (flags & (1u << c)) ? 0.f : g_rgb_in[c];
   float dv[3] = {p[0] - campos[0], p[1] - campos[1], p[2] - campos[2]};
@@ -326,35 +331,37 @@ MGS_HD void sh_backward(int deg, int K, const float* sh, const float p[3], const
   const float inv = 1.0f / sqrtf(n2);
   const float x = dv[0] * inv, y = dv[1] * inv, z = dv[2] * inv;
   float ddir[3] = {0.f, 0.f, 0.f};
-  for (int k = 0; k < K * 3; k++) dsh[k] = 0.f;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
   for (int c = 0; c < 3; c++) {
     const float gc = g[c];
-    dsh[c] = SH_C0 * gc;
+    emit(c, SH_C0 * gc);
     if (deg > 0) {
-      dsh[3 + c] = -SH_C1 * y * gc;
-      dsh[6 + c] = SH_C1 * z * gc;
-      dsh[9 + c] = -SH_C1 * x * gc;
+      emit(3 + c, -SH_C1 * y * gc);
+      emit(6 + c, SH_C1 * z * gc);
+      emit(9 + c, -SH_C1 * x * gc);
       float dx = -SH_C1 * sh[9 + c], dy = -SH_C1 * sh[3 + c], dz = SH_C1 * sh[6 + c];
       if (deg > 1) {
         const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-        dsh[12 + c] = SH_C2_0 * xy * gc;
-        dsh[15 + c] = SH_C2_1 * yz * gc;
-        dsh[18 + c] = SH_C2_2 * (2.f * zz - xx - yy) * gc;
-        dsh[21 + c] = SH_C2_3 * xz * gc;
-        dsh[24 + c] = SH_C2_4 * (xx - yy) * gc;
+        emit(12 + c, SH_C2_0 * xy * gc);
+        emit(15 + c, SH_C2_1 * yz * gc);
+        emit(18 + c, SH_C2_2 * (2.f * zz - xx - yy) * gc);
+        emit(21 + c, SH_C2_3 * xz * gc);
+        emit(24 + c, SH_C2_4 * (xx - yy) * gc);
         dx += SH_C2_0 * y * sh[12 + c] + SH_C2_2 * (-2.f * x) * sh[18 + c] +
               SH_C2_3 * z * sh[21 + c] + SH_C2_4 * 2.f * x * sh[24 + c];
         dy += SH_C2_0 * x * sh[12 + c] + SH_C2_1 * z * sh[15 + c] +
               SH_C2_2 * (-2.f * y) * sh[18 + c] + SH_C2_4 * (-2.f * y) * sh[24 + c];
         dz += SH_C2_1 * y * sh[15 + c] + SH_C2_2 * 4.f * z * sh[18 + c] + SH_C2_3 * x * sh[21 + c];
         if (deg > 2) {
-          dsh[27 + c] = SH_C3_0 * y * (3.f * xx - yy) * gc;
-          dsh[30 + c] = SH_C3_1 * xy * z * gc;
-          dsh[33 + c] = SH_C3_2 * y * (4.f * zz - xx - yy) * gc;
-          dsh[36 + c] = SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy) * gc;
-          dsh[39 + c] = SH_C3_4 * x * (4.f * zz - xx - yy) * gc;
-          dsh[42 + c] = SH_C3_5 * z * (xx - yy) * gc;
-          dsh[45 + c] = SH_C3_6 * x * (xx - 3.f * yy) * gc;
+          emit(27 + c, SH_C3_0 * y * (3.f * xx - yy) * gc);
+          emit(30 + c, SH_C3_1 * xy * z * gc);
+          emit(33 + c, SH_C3_2 * y * (4.f * zz - xx - yy) * gc);
+          emit(36 + c, SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy) * gc);
+          emit(39 + c, SH_C3_4 * x * (4.f * zz - xx - yy) * gc);
+          emit(42 + c, SH_C3_5 * z * (xx - yy) * gc);
+          emit(45 + c, SH_C3_6 * x * (xx - 3.f * yy) * gc);
           dx += SH_C3_0 * sh[27 + c] * 6.f * xy + SH_C3_1 * sh[30 + c] * yz +
                 SH_C3_2 * sh[33 + c] * (-2.f * xy) + SH_C3_3 * sh[36 + c] * (-6.f * xz) +
                 SH_C3_4 * sh[39 + c] * (4.f * zz - 3.f * xx - yy) +
@@ -378,6 +385,13 @@ MGS_HD void sh_backward(int deg, int K, const float* sh, const float p[3], const
     dmean[1] += (ddir[1] - y * dot) * inv;
     dmean[2] += (ddir[2] - z * dot) * inv;
   }
+}
+
+// array form: dsh[3 K], bands above the active degree zero
+MGS_HD void sh_backward(int deg, int K, const float* sh, const float p[3], const float campos[3],
+                        uint32_t flags, const float g_rgb_in[3], float* dsh, float dmean[3]) {
+  for (int k = 3 * (deg + 1) * (deg + 1); k < K * 3; k++) dsh[k] = 0.f;
+  sh_backward_emit(deg, sh, p, campos, flags, g_rgb_in, dmean, [&](int k, float v) { dsh[k] = v; });
 }
 
 MGS_HD void project_gaussian_backward(const Camera& cam, const float p[3], const float* scale,

@@ -118,9 +118,9 @@ __global__ __launch_bounds__(512) void k_pose_adam_update(mgs_pose_adam_args A) 
   if (A.sticky_converged && A.converged && *A.converged != 0) return;    // the reference has left its loop
   float grad_scale = 1.f;
   if (A.loss_partials && A.loss_norm_mode == 1) {
-    // tracking objective = sqrt(sum h^2): the gradients summed above lack its 1 / loss
-    const float l = sqrtf(s_loss[0]);
-    const float inv = l > 0.f ? 1.f / l : 0.f;
+    // tracking objective = (sum |h|^p)^(1/p): the gradients summed above lack its loss^(1-p) (1 / loss for p = 2)
+    float l, inv;
+    norm_finish(s_loss[0], norm_p(A.loss_pnorm), l, inv);
     grad_scale = inv * (A.loss_grad_out ? A.loss_grad_out[0] : 1.f);
     if (A.loss_view) { A.loss_view[0] = l; A.loss_view[1] = inv; }
   } else if (A.loss_partials) {
@@ -212,11 +212,13 @@ __global__ __launch_bounds__(512) void k_pose_adam_update(mgs_pose_adam_args A) 
       A.best[19] = best_count;
     }
     A.best[20] = best_count + 1.f;
+    if (A.l1_partials) A.best[21] = s_l1;      // criterion of THIS iteration's render (a trace for tests / logging)
   }
   if (have_T) {
     if (move) for (int i = 0; i < 12; i++) A.T[i] = Tm[i];
     const float n2 = th[0] * th[0] + th[1] * th[1] + th[2] * th[2] + rho[0] * rho[0] + rho[1] * rho[1] +
                      rho[2] * rho[2];
+    if (A.best) A.best[22] = sqrtf(n2);        // |tau| of the step just applied (what the convergence test sees)
     if (A.converged) *A.converged = n2 < A.converged_threshold * A.converged_threshold ? 1 : 0;
     if (want_mats) {   // matrices of the updated pose: view = T^T, full = view @ projection
       for (int i = 0; i < 4; i++)
@@ -256,35 +258,38 @@ __device__ __forceinline__ float block_sum(float v, float* s_red) {
   return t;
 }
 
-// partial[b] = sum over the block's pixels of h^2 (3 channels)
+// partial[b] = sum over the block's pixels of |h|^p (3 channels)
 __global__ __launch_bounds__(kLossBlock) void k_track_loss_fwd(mgs_tracking_loss_args A) {
   __shared__ float s_red[kLossBlock / 64];
   const float gain = fabsf(A.exposure_a[0]) + A.exposure_eps, bias = A.exposure_b[0];
+  const float pn = norm_p(A.pnorm);
   const size_t HW = (size_t)A.num_pixels;
   float acc = 0.f;
   for (size_t p = (size_t)blockIdx.x * kLossBlock + threadIdx.x; p < HW; p += (size_t)gridDim.x * kLossBlock) {
     const float om = A.opacity[p] * (A.mask ? A.mask[p] : 1.f);
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-      float dh;
+      float dh, phi, gam;
       const float h = huber(om * (gain * A.image[c * HW + p] + bias - A.gt[c * HW + p]), A.huber_delta, dh);
-      acc += h * h;
+      norm_terms(h, pn, phi, gam);
+      acc += phi;
     }
   }
   const float t = block_sum(acc, s_red);
   if (threadIdx.x == 0) A.partial[blockIdx.x] = t;
 }
 
-// loss = sqrt(sum partial); scalars[0] = loss, scalars[1] = 1/loss (0 if loss == 0)
+// loss = (sum partial)^(1/p); scalars[0] = loss, scalars[1] = loss^(1-p) (1/loss for p = 2; 0 if loss == 0)
 __global__ __launch_bounds__(kLossBlock) void k_track_loss_finish(mgs_tracking_loss_args A, int nblk) {
   __shared__ float s_red[kLossBlock / 64];
   float acc = 0.f;
   for (int i = threadIdx.x; i < nblk; i += kLossBlock) acc += A.partial[i];
   const float t = block_sum(acc, s_red);
   if (threadIdx.x == 0) {
-    const float l = sqrtf(t);
+    float l, sc;
+    norm_finish(t, norm_p(A.pnorm), l, sc);
     A.scalars[0] = l;
-    A.scalars[1] = l > 0.f ? 1.f / l : 0.f;
+    A.scalars[1] = sc;
   }
 }
 
@@ -297,12 +302,13 @@ __global__ __launch_bounds__(kLossBlock) void k_track_loss_bwd(mgs_tracking_loss
   const float a = A.exposure_a[0];
   const float gain = fabsf(a) + A.exposure_eps, bias = A.exposure_b[0];
   const float sgn = a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f);
-  float inv_loss = 0.f;
+  const float pn = norm_p(A.pnorm);
+  float inv_loss = 0.f;      // loss^(1-p), the factor of the norm's derivative
   if (nfwd > 0) {
     float acc = 0.f;
     for (int i = threadIdx.x; i < nfwd; i += kLossBlock) acc += A.partial[i];
-    const float l = sqrtf(block_sum(acc, s_red));
-    inv_loss = l > 0.f ? 1.f / l : 0.f;
+    float l;
+    norm_finish(block_sum(acc, s_red), pn, l, inv_loss);
     if (blockIdx.x == 0 && threadIdx.x == 0) { A.scalars[0] = l; A.scalars[1] = inv_loss; }
     __syncthreads();
   } else {
@@ -316,9 +322,10 @@ __global__ __launch_bounds__(kLossBlock) void k_track_loss_bwd(mgs_tracking_loss
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       const float im = A.image[c * HW + p];
-      float dh;
+      float dh, phi, gam;
       const float h = huber(om * (gain * im + bias - A.gt[c * HW + p]), A.huber_delta, dh);
-      const float gr = k * h * dh * om;       // dL/d(residual before opacity) * om
+      norm_terms(h, pn, phi, gam);
+      const float gr = k * gam * dh * om;     // dL/d(residual before opacity) * om
       A.grad_image[c * HW + p] = gr * gain;
       ga += gr * im;
       gb += gr;
@@ -341,9 +348,9 @@ __global__ __launch_bounds__(kLossBlock) void k_track_loss_bwd_finish(mgs_tracki
   if (threadIdx.x == 0) { A.grad_a[0] = ta; A.grad_b[0] = tb; }
 }
 
-// One pass (mgs_tracking_loss_onepass): block sums of h^2, the image gradient and the exposure
-// partials WITHOUT the 1 / loss factor of the norm's derivative; k_pose_adam_update applies it
-// (loss_norm_mode).  partial = [n] sum h^2 | [n] d/da | [n] d/db | [n] sum |r| (before Huber).
+// One pass (mgs_tracking_loss_onepass): block sums of |h|^p, the image gradient and the exposure
+// partials WITHOUT the loss^(1-p) factor of the norm's derivative (1 / loss for p = 2); k_pose_adam_update applies it
+// (loss_norm_mode).  partial = [n] sum |h|^p | [n] d/da | [n] d/db | [n] sum |r| (before Huber).
 // VEC: four consecutive pixels per thread and trip through 16-B loads / stores (as k_map_loss_fused<true>).
 template <bool VEC>
 __global__ __launch_bounds__(kLossBlock) void k_track_loss_onepass(mgs_tracking_loss_args A) {
@@ -352,14 +359,16 @@ __global__ __launch_bounds__(kLossBlock) void k_track_loss_onepass(mgs_tracking_
   const float gain = fabsf(a) + A.exposure_eps, bias = A.exposure_b[0];
   const float sgn = a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f);
   const size_t HW = (size_t)A.num_pixels;
+  const float pn = norm_p(A.pnorm);
   float acc = 0.f, ga = 0.f, gb = 0.f, l1 = 0.f;
   auto sample = [&](float om, float im, float gt) {      // one colour sample: sums + d/d image
-    float dh;
+    float dh, phi, gam;
     const float r = om * (gain * im + bias - gt);
     l1 += fabsf(r);
     const float h = huber(r, A.huber_delta, dh);
-    acc += h * h;
-    const float gr = h * dh * om;
+    norm_terms(h, pn, phi, gam);
+    acc += phi;
+    const float gr = gam * dh * om;
     ga += gr * im;
     gb += gr;
     return gr * gain;
@@ -496,10 +505,10 @@ __global__ __launch_bounds__(256) void k_lm_solve_step(mgs_lm_step_args A) {
   }
   for (int i = 0; i < 8; i++) A.x_out[i] = (float)x[i];
   bool converged = false;
+  double xn2 = 0.0;
+  for (int i = 0; i < 8; i++) xn2 += x[i] * x[i];
   if (A.lm_state) {
-    double n2 = 0.0;
-    for (int i = 0; i < 8; i++) n2 += x[i] * x[i];
-    converged = sqrt(n2) < (double)A.converged_threshold;
+    converged = sqrt(xn2) < (double)A.converged_threshold;
     A.lm_state[3] = converged ? 1.f : 0.f;
   }
   if (A.best && A.loss && A.T) {     // best iterate = the state this iteration rendered (before the step)
@@ -512,6 +521,8 @@ __global__ __launch_bounds__(256) void k_lm_solve_step(mgs_lm_step_args A) {
       A.best[19] = count;
     }
     A.best[20] = count + 1.f;
+    A.best[21] = loss_in;                      // criterion of this iteration's render
+    A.best[22] = (float)sqrt(xn2);             // |x| of this iteration's step
   }
   if (converged) return;             // slam_frontend.py:699-706: the converged step is never assigned
   if (A.T) {
@@ -1016,12 +1027,16 @@ int32_t mgs_sketch_residual(const mgs_sketch_residual_args* a, void* stream) {
 
 int32_t mgs_tracking_loss_partial_count(int64_t num_pixels) { return 4 * loss_blocks(num_pixels); }
 
+// p of the norm: <= 0 selects 2; 0 < p < 1 is not a norm (and its derivative is unbounded at 0)
+static bool pnorm_ok(float p) { return !(p > 0.f && p < 1.f) && p == p; }
+
 // Fused form used by mgs_tracking_iteration: forward sums + backward in two launches; the
 // exposure partials ([2, nblk]) start at partial + nblk.
 int32_t mgs_tracking_loss_fused(const mgs_tracking_loss_args* a, int32_t* nblk_out, void* stream) {
   if (!a || !a->image || !a->opacity || !a->gt || !a->exposure_a || !a->exposure_b || !a->partial ||
       !a->scalars || !a->grad_out || !a->grad_image || a->num_pixels < 1)
     return MGS_ERR_BAD_ARGUMENT;
+  if (!pnorm_ok(a->pnorm)) return MGS_ERR_BAD_ARGUMENT;
   const int nb = loss_blocks(a->num_pixels);
   launch("track_loss_fwd", k_track_loss_fwd, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a);
   launch("track_loss_bwd", k_track_loss_bwd, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a, nb);
@@ -1033,6 +1048,7 @@ int32_t mgs_tracking_loss_onepass(const mgs_tracking_loss_args* a, int32_t* nblk
   if (!a || !a->image || !a->opacity || !a->gt || !a->exposure_a || !a->exposure_b || !a->partial ||
       !a->grad_image || a->num_pixels < 1)
     return MGS_ERR_BAD_ARGUMENT;
+  if (!pnorm_ok(a->pnorm)) return MGS_ERR_BAD_ARGUMENT;
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const bool vec = a->num_pixels % 4 == 0 && al16(a->image) && al16(a->opacity) && al16(a->gt) && al16(a->mask) &&
                    al16(a->grad_image);
@@ -1051,6 +1067,7 @@ int32_t mgs_tracking_loss_forward(const mgs_tracking_loss_args* a, void* stream)
   if (!a || !a->image || !a->opacity || !a->gt || !a->exposure_a || !a->exposure_b || !a->partial ||
       !a->scalars || a->num_pixels < 1)
     return MGS_ERR_BAD_ARGUMENT;
+  if (!pnorm_ok(a->pnorm)) return MGS_ERR_BAD_ARGUMENT;
   const int nb = loss_blocks(a->num_pixels);
   launch("track_loss_fwd", k_track_loss_fwd, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a);
   launch("track_loss_finish", k_track_loss_finish, dim3(1), dim3(kLossBlock), (hipStream_t)stream, *a, nb);
@@ -1061,6 +1078,7 @@ int32_t mgs_tracking_loss_backward(const mgs_tracking_loss_args* a, void* stream
   if (!a || !a->image || !a->opacity || !a->gt || !a->exposure_a || !a->exposure_b || !a->partial ||
       !a->scalars || !a->grad_out || !a->grad_image || !a->grad_a || !a->grad_b || a->num_pixels < 1)
     return MGS_ERR_BAD_ARGUMENT;
+  if (!pnorm_ok(a->pnorm)) return MGS_ERR_BAD_ARGUMENT;
   const int nb = loss_blocks(a->num_pixels);
   launch("track_loss_bwd", k_track_loss_bwd, dim3(nb), dim3(kLossBlock), (hipStream_t)stream, *a, 0);
   launch("track_loss_bwd_fin", k_track_loss_bwd_finish, dim3(1), dim3(kLossBlock), (hipStream_t)stream, *a, nb);

@@ -87,7 +87,17 @@ class Pipe:
 DEFAULT_CONFIG = {"Training": {"monocular": True, "rgb_boundary_threshold": 0.01,
                                "lr": {"cam_rot_delta": 0.003, "cam_trans_delta": 0.001,
                                       "exposure_a": 0.02, "exposure_b": 0.02},
-                               "RGN": {"use_huber": True, "huber_delta": 0.01}}}
+                               "RGN": {"use_huber": True, "huber_delta": 0.01, "pnorm": 1}}}
+
+
+def tracking_norm(config=DEFAULT_CONFIG):
+    """(huber_delta, p) of the first-order tracking objective as the reference chooses them
+    (slam_frontend.py:596-600): Huber + L2 when RGN.use_huber, else no Huber (delta 0) and the
+    RGN.pnorm-norm (configs/mono/tum/base_config.yaml:247-249 ships use_huber True, pnorm 1)."""
+    rgn = config["Training"]["RGN"]
+    if rgn["use_huber"]:
+        return float(rgn["huber_delta"]), 2.0
+    return 0.0, float(rgn["pnorm"])
 
 
 def make_pose_optimizer(viewpoint: ViewCamera, config=DEFAULT_CONFIG):
@@ -102,20 +112,21 @@ def make_pose_optimizer(viewpoint: ViewCamera, config=DEFAULT_CONFIG):
 def tracking_step_first_order(viewpoint, gaussians, pose_optimizer, background, pipe=Pipe,
                               config=DEFAULT_CONFIG):
     """One first-order tracking iteration (slam_frontend.py:493-630): render, per-pixel
-    residual, Huber + L2 norm, backward, Adam on (rot, trans, exposure), update_pose."""
+    residual, Huber + L2 norm (or the RGN.pnorm-norm without Huber, :596-600), backward, Adam on (rot, trans, exposure), update_pose."""
     render_pkg = render(viewpoint, gaussians, pipe, background)
     res = get_loss_tracking_per_pixel(config, render_pkg["render"], render_pkg["depth"],
                                       render_pkg["opacity"], viewpoint)
     # the reference's best-iterate criterion: ||residual||_1 before Huber (slam_frontend.py:510)
     render_pkg["tracking_l1"] = res.detach().abs().sum()
-    rgn = config["Training"]["RGN"]
-    if rgn["use_huber"]:
-        res = HuberLoss.apply(res, rgn["huber_delta"])
-    loss = torch.norm(res.flatten(), p=2)
+    delta, p = tracking_norm(config)
+    if delta > 0:
+        res = HuberLoss.apply(res, delta)
+    loss = torch.norm(res.flatten(), p=p)
     pose_optimizer.zero_grad()
     loss.backward()
     with torch.no_grad():
         pose_optimizer.step()
+        render_pkg["tracking_step_norm"] = torch.cat([viewpoint.cam_trans_delta, viewpoint.cam_rot_delta]).norm()
         converged = update_pose(viewpoint)
     return loss.detach(), converged, render_pkg
 
@@ -127,12 +138,11 @@ def tracking_step_first_order_fused(viewpoint, gaussians, fused_optimizer, backg
     convergence flag as a device tensor (no host sync inside)."""
     from .tracking_fused import tracking_loss
     render_pkg = render(viewpoint, gaussians, pipe, background)
-    rgn = config["Training"]["RGN"]
+    delta, p = tracking_norm(config)
     with torch.no_grad():
         render_pkg["tracking_l1"] = get_loss_tracking_per_pixel(
             config, render_pkg["render"], render_pkg["depth"], render_pkg["opacity"], viewpoint).abs().sum()
-    loss = tracking_loss(render_pkg["render"], render_pkg["opacity"], viewpoint,
-                         rgn["huber_delta"] if rgn["use_huber"] else 0.0)
+    loss = tracking_loss(render_pkg["render"], render_pkg["opacity"], viewpoint, delta, p)
     fused_optimizer.zero_grad()
     loss.backward()
     converged = fused_optimizer.step()
@@ -172,24 +182,29 @@ def gen_forward_sketch_args(height, width, repeat_dim, stack_dim, sketch_dim, de
 
 def sketch_args_from_buckets(bucket: torch.Tensor, weights: torch.Tensor, height, width, stack_dim,
                              sketch_dim):
-    """forward_sketch_args (repeat_dim = 1) for a given bucket partition: `bucket` [H*W] =
-    stack * sketch_dim + k or -1 and `weights` [H*W] = +-1, as mgs_sketch_assign produces them."""
+    """forward_sketch_args for given bucket partitions: `bucket` [H*W] or [repeat, H*W] =
+    stack * sketch_dim + k or -1 and `weights` (same shape) = +-1, as mgs_sketch_assign produces them."""
     dev = bucket.device
     m, d = height * width, stack_dim * sketch_dim
     chunk = m // d
-    b = bucket.long()
-    idx = torch.full((stack_dim, m), -1, dtype=torch.int32, device=dev)
-    p = torch.nonzero(b >= 0).squeeze(1)
-    idx[b[p] // sketch_dim, p] = (b[p] % sketch_dim).to(torch.int32)
-    order = p[torch.argsort(b[p], stable=True)]                   # pixels grouped by bucket
-    rows = (order // width).view(1, stack_dim, sketch_dim, chunk).to(torch.int32)
-    cols = (order % width).view(1, stack_dim, sketch_dim, chunk).to(torch.int32)
-    return {"sketch_mode": 1, "repeat_dim": 1, "stack_dim": stack_dim, "sketch_dim": sketch_dim,
-            "sketch_indices": idx.reshape(1, stack_dim, height, width),
+    bucket, weights = bucket.reshape(-1, m), weights.reshape(-1, m)
+    R = bucket.shape[0]
+    idx = torch.full((R, stack_dim, m), -1, dtype=torch.int32, device=dev)
+    rows = torch.empty(R, stack_dim, sketch_dim, chunk, dtype=torch.int32, device=dev)
+    cols = torch.empty_like(rows)
+    for r in range(R):
+        b = bucket[r].long()
+        p = torch.nonzero(b >= 0).squeeze(1)
+        idx[r, b[p] // sketch_dim, p] = (b[p] % sketch_dim).to(torch.int32)
+        order = p[torch.argsort(b[p], stable=True)]                   # pixels grouped by bucket
+        rows[r] = (order // width).view(stack_dim, sketch_dim, chunk).to(torch.int32)
+        cols[r] = (order % width).view(stack_dim, sketch_dim, chunk).to(torch.int32)
+    return {"sketch_mode": 1, "repeat_dim": R, "stack_dim": stack_dim, "sketch_dim": sketch_dim,
+            "sketch_indices": idx.reshape(R, stack_dim, height, width),
             "rand_indices": (rows, cols), "rand_indices_row": rows, "rand_indices_col": cols,
             "sketch_dtau": torch.empty(stack_dim, sketch_dim, 6, device=dev, requires_grad=True),
             "sketch_dexposure": torch.empty(stack_dim, sketch_dim, 2, device=dev, requires_grad=True),
-            "chunk_size": chunk, "rand_weights": weights.reshape(1, height, width).float()}
+            "chunk_size": chunk, "rand_weights": weights.reshape(R, height, width).float()}
 
 
 def tracking_step_second_order(viewpoint, gaussians, background, lambda_, repeat_dim=1,
@@ -270,7 +285,7 @@ def track_frame(viewpoint, gaussians, background, first_order_iters=40, second_o
                 use_first_order_best=True, use_best_loss=True, pipe=Pipe, config=DEFAULT_CONFIG,
                 stack_dim=16, sketch_dim=64, initial_lambda=1e-3, min_lambda=1e-6, max_lambda=1e7,
                 increase_factor=5.0, decrease_factor=5.0, second_order_converged_threshold=1e-5,
-                generator=None, fused=False, fsa_fn=None):
+                generator=None, fused=False, fsa_fn=None, repeat_dim=1, trace=None):
     """The reference's tracking loop for one frame, reference-shaped Python on the HIP rasteriser
     (slam_frontend.py:455-822 with override_mode "none"): first-order iterations (Adam on the pose
     deltas and the exposure; a converged one leaves the whole loop, :623-626), then sketched LM
@@ -279,7 +294,8 @@ def track_frame(viewpoint, gaussians, background, first_order_iters=40, second_o
     phase starts from the best first-order state (`use_first_order_best`, :465-470); the frame ends
     at the best state and returns ITS render_pkg (`use_best_loss`, :819-822).
     Returns (render_pkg, best_l1, best_iteration, iterations).  `fsa_fn(i)` may supply the sketch
-    arguments of second-order iteration i (tests: the native tracker's partitions)."""
+    arguments of second-order iteration i (tests: the native tracker's partitions).  `trace` (a list)
+    receives per iteration (L1 of its render, |step| it took, converged)."""
     if fused:
         from .tracking_fused import FusedPoseOptimizer
         lr = config["Training"]["lr"]
@@ -310,16 +326,20 @@ def track_frame(viewpoint, gaussians, background, first_order_iters=40, second_o
             _, converged, pkg = step(viewpoint, gaussians, opt, background, pipe, config)
             converged = bool(converged)
             l1 = float(pkg["tracking_l1"])
+            step_norm = pkg.get("tracking_step_norm")
         else:
             fsa = None if fsa_fn is None else fsa_fn(itr - first_order_iters)
             l1_t, x, _, _, pkg = tracking_step_second_order(
-                viewpoint, gaussians, background, lambda_rule, 1, stack_dim, sketch_dim, pipe, config,
+                viewpoint, gaussians, background, lambda_rule, repeat_dim, stack_dim, sketch_dim, pipe, config,
                 generator, fused_solve=True, fsa=fsa, return_pkg=True)
             l1 = float(l1_t)
-            converged = bool(x.norm() < second_order_converged_threshold)
+            step_norm = x.norm()
+            converged = bool(step_norm < second_order_converged_threshold)
             if converged:                        # the converged step is never assigned (:699-706)
                 state.assign(viewpoint)
         it += 1
+        if trace is not None:
+            trace.append((l1, None if step_norm is None else float(step_norm), converged))
         if l1 < best_l1:
             best_l1, best_state, best_pkg, best_it = l1, state, pkg, itr
         if converged:

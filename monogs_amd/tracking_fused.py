@@ -3,7 +3,7 @@ optimiser step + update_pose, each a couple of launches instead of ~100 PyTorch 
 
 Semantics are those of the reference's PyTorch code (checked in tests against
 monogs_amd/losses.py and torch.optim.Adam + monogs_amd/pose.update_pose):
-  * loss     utils/slam_utils.py:188-205 (+ Huber :58-75, L2 norm slam_frontend.py:596-598)
+  * loss     utils/slam_utils.py:188-205 (+ Huber :58-75, p-norm slam_frontend.py:596-600)
   * optimise utils/slam_frontend.py:364-392,606-615 and utils/pose_utils.py:88-98
 """
 from __future__ import annotations
@@ -21,7 +21,7 @@ def _stream(dev):
 
 class _TrackingLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, image, opacity, gt, mask, exposure_a, exposure_b, exposure_eps, huber_delta):
+    def forward(ctx, image, opacity, gt, mask, exposure_a, exposure_b, exposure_eps, huber_delta, pnorm=2.0):
         dev = image.device
         if dev.type != "cuda":
             raise RuntimeError("fused tracking loss runs on the GPU only; use monogs_amd.losses on CPU")
@@ -38,20 +38,21 @@ class _TrackingLoss(torch.autograd.Function):
         a.mask = None if mask_c is None else mask_c.data_ptr()
         a.exposure_a, a.exposure_b = exposure_a.data_ptr(), exposure_b.data_ptr()
         a.exposure_eps, a.huber_delta, a.num_pixels = float(exposure_eps), float(huber_delta), HW
+        a.pnorm = float(pnorm)
         a.partial, a.scalars = partial.data_ptr(), scalars.data_ptr()
         _cabi.check(lib.mgs_tracking_loss_forward(C.byref(a), _stream(dev)), "mgs_tracking_loss_forward")
         ctx.save_for_backward(image_c, opa_c, gt_c, mask_c, exposure_a, exposure_b, partial, scalars)
-        ctx.consts = (float(exposure_eps), float(huber_delta), HW)
+        ctx.consts = (float(exposure_eps), float(huber_delta), HW, float(pnorm))
         return scalars[0].clone()
 
     @staticmethod
     def backward(ctx, grad_out):
         if grad_out is None:
-            return (None,) * 8
+            return (None,) * 9
         image_c, opa_c, gt_c, mask_c, exposure_a, exposure_b, partial, scalars = ctx.saved_tensors
         dev = image_c.device
         lib = _cabi.lib()
-        eps, delta, HW = ctx.consts
+        eps, delta, HW, pnorm = ctx.consts
         go = grad_out.detach().float().reshape(1).contiguous()
         g_img = torch.empty_like(image_c)
         g_a = torch.empty(1, dtype=torch.float32, device=dev)
@@ -61,20 +62,22 @@ class _TrackingLoss(torch.autograd.Function):
         a.mask = None if mask_c is None else mask_c.data_ptr()
         a.exposure_a, a.exposure_b = exposure_a.data_ptr(), exposure_b.data_ptr()
         a.exposure_eps, a.huber_delta, a.num_pixels = eps, delta, HW
+        a.pnorm = pnorm
         a.partial, a.scalars = partial.data_ptr(), scalars.data_ptr()
         a.grad_out, a.grad_image = go.data_ptr(), g_img.data_ptr()
         a.grad_a, a.grad_b = g_a.data_ptr(), g_b.data_ptr()
         _cabi.check(lib.mgs_tracking_loss_backward(C.byref(a), _stream(dev)), "mgs_tracking_loss_backward")
         return (g_img, None, None, None, g_a.reshape(exposure_a.shape), g_b.reshape(exposure_b.shape),
-                None, None)
+                None, None, None)
 
 
-def tracking_loss(image, opacity, viewpoint, huber_delta=0.01):
-    """|| Huber( opacity * mask * ((|a|+eps) image + b - gt) ) ||_2 for `viewpoint`
-    (attributes original_image, rgb_pixel_mask_mapping, exposure_a/b/eps)."""
+def tracking_loss(image, opacity, viewpoint, huber_delta=0.01, pnorm=2.0):
+    """|| Huber( opacity * mask * ((|a|+eps) image + b - gt) ) ||_p for `viewpoint`
+    (attributes original_image, rgb_pixel_mask_mapping, exposure_a/b/eps).  The reference uses p = 2 with
+    Huber and RGN.pnorm without (slam_frontend.py:596-600): see slam_loops.tracking_norm."""
     mask = viewpoint.rgb_pixel_mask_mapping
     return _TrackingLoss.apply(image, opacity, viewpoint.original_image, mask, viewpoint.exposure_a,
-                               viewpoint.exposure_b, viewpoint.exposure_eps, huber_delta)
+                               viewpoint.exposure_b, viewpoint.exposure_eps, huber_delta, pnorm)
 
 
 class FusedPoseOptimizer:

@@ -32,7 +32,11 @@ class NativeTracker:
 
     def __init__(self, viewpoint, gaussians, background, huber_delta=0.01, lr_rot=0.003,
                  lr_trans=0.001, lr_a=0.02, lr_b=0.02, betas=(0.9, 0.999), eps=1e-8,
-                 converged_threshold=1e-4, capacity_margin=1.5):
+                 converged_threshold=1e-4, capacity_margin=1.5, pnorm=2.0):
+        # (huber_delta, pnorm) as slam_loops.tracking_norm(config) returns them: the reference's first-order
+        # objective is Huber + L2 when RGN.use_huber, else the RGN.pnorm-norm without Huber (huber_delta = 0),
+        # slam_frontend.py:596-600.  p = 1 and p = 2 ride in the forward blend's epilogue, any other p >= 1
+        # costs one more launch per iteration.
         vp = viewpoint
         dev = vp.T.device
         if dev.type != "cuda":
@@ -107,6 +111,9 @@ class NativeTracker:
         L.mask = None if self.mask is None else self.mask.data_ptr()
         L.exposure_a, L.exposure_b = vp.exposure_a.data_ptr(), vp.exposure_b.data_ptr()
         L.exposure_eps, L.huber_delta, L.num_pixels = float(vp.exposure_eps), float(huber_delta), H * W
+        if not (float(pnorm) >= 1.0):
+            raise ValueError(f"pnorm must be >= 1, got {pnorm}")
+        L.pnorm = float(pnorm)
         L.partial, L.scalars = self.partial.data_ptr(), self.scalars.data_ptr()
         A = a.adam
         self.exp_avg = torch.zeros(8, device=dev)
@@ -144,25 +151,31 @@ class NativeTracker:
     # ---- second order (sketched Levenberg-Marquardt, slam_frontend.py:455-710) ----------
     def enable_second_order(self, stack_dim=16, sketch_dim=64, initial_lambda=1e-3, max_lambda=1e7,
                             min_lambda=1e-6, increase_factor=5.0, decrease_factor=5.0,
-                            converged_threshold=1e-5, seed=0, keep_sketch=False):
+                            converged_threshold=1e-5, seed=0, keep_sketch=False, repeat_dim=1):
         """Allocate the sketch scratch; defaults are configs/mono/tum/base_config.yaml:255-268.
         `keep_sketch`: leave Sf / SJ of the last iteration readable (`self.sketch`) - the accumulators are
         then cleared by memset launches at the start of an iteration instead of by their consumer at its end
-        (four launches more per iteration)."""
+        (four launches more per iteration).  `repeat_dim` (base_config.yaml:258): that many sketched backward
+        passes over the one render of an iteration, each with its own partition, rows stacked
+        (slam_frontend.py:654-669)."""
         dev, HW = self.dev, self.H * self.W
         d = stack_dim * sketch_dim
+        R = int(repeat_dim)
+        if R < 1:
+            raise ValueError("repeat_dim must be >= 1")
         so = _cabi.TrackingSOArgs()
         C.memmove(C.byref(so.base), C.byref(self.args), C.sizeof(_cabi.TrackingIterArgs))
         sizes = _cabi.workspace_sizes(so.base.fwd.shape)
-        self.so_bucket = torch.empty(HW, dtype=torch.int32, device=dev)
-        self.so_weights = torch.empty(HW, device=dev)
-        self.so_accum = torch.zeros(9 * d + 4, device=dev)
+        self.so_bucket = torch.empty(R, HW, dtype=torch.int32, device=dev)
+        self.so_weights = torch.empty(R, HW, device=dev)
+        self.so_accum = torch.zeros(9 * R * d + 4, device=dev)
         # zero-filled once: the iteration's kernels keep the accumulators and the Jacobian rows zero
         # between calls (scratch_kept_zero), so no memset launches are needed per iteration
         self.so_sketch_ws = torch.zeros(int(sizes.sketch_bytes), dtype=torch.uint8, device=dev)
         self.lm_state = torch.tensor([initial_lambda, 0.0, 0.0, 0.0], device=dev)
+        self._lm_initial = self.lm_state.clone()
         self.so_x = torch.zeros(8, device=dev)
-        so.stack_dim, so.sketch_dim = stack_dim, sketch_dim
+        so.stack_dim, so.sketch_dim, so.repeat_dim = stack_dim, sketch_dim, R
         so.bucket, so.weights = self.so_bucket.data_ptr(), self.so_weights.data_ptr()
         so.accum, so.sketch_ws = self.so_accum.data_ptr(), self.so_sketch_ws.data_ptr()
         so.lm.lm_state, so.lm.x_out = self.lm_state.data_ptr(), self.so_x.data_ptr()
@@ -170,7 +183,7 @@ class NativeTracker:
         so.lm.min_lambda, so.lm.max_lambda = min_lambda, max_lambda
         so.lm.converged_threshold = converged_threshold
         so.scratch_kept_zero = 0 if keep_sketch else 1
-        self.so_args, self.so_d, self.so_seed, self.so_t = so, d, int(seed), 0
+        self.so_args, self.so_d, self.so_seed, self.so_t, self.so_repeat = so, R * d, int(seed), 0, R
 
     def step_second_order(self):
         """Enqueue one sketched LM iteration: fresh random bucket partition, forward, sketched
@@ -193,7 +206,7 @@ class NativeTracker:
 
     @property
     def sketch(self):
-        """(Sf [d], SJ [d, 8]) of the last second-order iteration (views / a small cat); needs
+        """(Sf [R d], SJ [R d, 8]) of the last second-order iteration (views / a small cat); needs
         enable_second_order(keep_sketch=True) - otherwise the LM kernel has zeroed them again."""
         if self.so_args.scratch_kept_zero:
             raise RuntimeError("enable_second_order(keep_sketch=True) is needed to read the sketch back")
@@ -249,6 +262,24 @@ class NativeTracker:
         self._alloc_bins(self.args, int(worst * self.capacity_margin))
         return False
 
+    def reset_frame(self):
+        """The per-frame state of the reference's loop (slam_frontend.py:423-429): best iterate = none,
+        lambda_ = initial_lambda, no previous second-order loss, and both sticky convergence flags cleared
+        (once set they turn every later step() / step_second_order() into a no-op: a caller driving its own
+        step loop over several frames calls this between frames; run() does).  The Adam moments are NOT
+        reset here: the reference builds a new optimiser per frame, so does whoever builds a tracker per
+        frame; reuse across frames goes through `reset_optimizer()`."""
+        self.reset_best()
+        self.converged.zero_()
+        if hasattr(self, "lm_state"):
+            self.lm_state.copy_(self._lm_initial)
+
+    def reset_optimizer(self):
+        """torch.optim.Adam(opt_params) of a new frame (slam_frontend.py:455): zero moments, step count 0."""
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self.t = 0
+
     # ---- best iterate (slam_frontend.py:423-425, 465-470, 523-528, 819-822) -----------------
     def reset_best(self):
         self.best.zero_()
@@ -258,6 +289,18 @@ class NativeTracker:
     def best_loss(self):
         """||residual||_1 of the best iterate so far (device scalar; inf before the first iteration)."""
         return self.best[0]
+
+    @property
+    def last_l1(self):
+        """||residual||_1 (before Huber) of the render the LAST iteration started from - the reference's
+        loss_tracking_scalar (slam_frontend.py:510); device scalar."""
+        return self.best[21]
+
+    @property
+    def last_step_norm(self):
+        """|tau| applied by the last first-order iteration's update_pose (pose_utils.py:88-98), or |x| of the
+        last LM solve (slam_frontend.py:693); device scalar."""
+        return self.best[22]
 
     def best_iteration(self) -> int:
         """0-based index (first- and second-order iterations counted together) of the best iterate
@@ -334,8 +377,7 @@ class NativeTracker:
         If ANY iteration overflowed the fixed pair capacity, pose, exposure, optimiser and best-iterate
         state are restored from the snapshot taken on entry, the workspaces grow and the run is
         repeated: no truncated render ever reaches the result.  Returns the iterations enqueued."""
-        self.reset_best()
-        self.converged.zero_()
+        self.reset_frame()
         keep = self._snapshot()
         for attempt in range(4):
             it = 0
@@ -351,13 +393,24 @@ class NativeTracker:
                 if use_first_order_best:
                     self.assign_best()
                 done = 0
+                last = None
                 while done < second_order_iters:
                     for _ in range(min(check_every, second_order_iters - done)):
+                        if done == second_order_iters - 1 and not use_best_loss:
+                            # The reference computes a step in its last iteration but only ever APPLIES a step at
+                            # the top of the next one (slam_frontend.py:474-479): the frame ends at the state the
+                            # last iteration rendered.  (With use_best_loss the best rendered state wins anyway.)
+                            vp = self.vp
+                            last = (vp.T.detach().clone(), vp.exposure_a.detach().clone(), vp.exposure_b.detach().clone())
                         self.step_second_order()
                         done += 1
                         it += 1
                     if float(self.lm_state[3].item()) != 0.0:
                         break
+                if last is not None:
+                    with torch.no_grad():
+                        self.vp.T.copy_(last[0]); self.vp.exposure_a.copy_(last[1]); self.vp.exposure_b.copy_(last[2])
+                    self._matrices_fresh = False
             if use_best_loss:
                 self.assign_best()
                 if render_best:

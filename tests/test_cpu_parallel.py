@@ -91,7 +91,7 @@ def _oracle_render(view, pc, pipe, bg, **_):
             "depth": dep, "opacity": opa, "n_touched": nt}
 
 
-def _mapping_fixture():
+def _mapping_fixture(n_views=4):
     import math
     from monogs_amd import synthetic as S
     from monogs_amd.parallel import view_pose
@@ -103,7 +103,7 @@ def _mapping_fixture():
     gauss = GaussianParams(sc.means3D, sc.log_scales, sc.rot, sc.opacity_logit, sc.features_dc)
     g = torch.Generator().manual_seed(9)
     views = []
-    for i in range(4):
+    for i in range(n_views):
         img = torch.rand(3, H, W, generator=g)
         v = ViewCamera(i, img, view_pose(i), cam.projmatrix_raw, fovx, fovy, H, W, "cpu")
         with torch.no_grad():
@@ -124,12 +124,12 @@ def _optimizers(gauss, views):
     return gopt, torch.optim.Adam(groups)
 
 
-def _run_mapping(gauss, views, indices, bucket, iters=2):
+def _run_mapping(gauss, views, indices, bucket, iters=2, pose_window=3):
     from monogs_amd.slam_loops import mapping_step
     gopt, kopt = _optimizers(gauss, views)
     out = None
     for _ in range(iters):
-        out = mapping_step(views, gauss, gopt, kopt, torch.zeros(3), pose_window=3, bucket=bucket,
+        out = mapping_step(views, gauss, gopt, kopt, torch.zeros(3), pose_window=pose_window, bucket=bucket,
                            window_indices=indices, render_fn=_oracle_render)
     state = {"xyz": gauss._xyz.detach().clone(), "scaling": gauss._scaling.detach().clone(),
              "opacity": gauss._opacity.detach().clone(), "rot": gauss._rotation.detach().clone(),
@@ -176,3 +176,50 @@ def test_sharded_mapping_step_matches_single_process_world2():
                     np.testing.assert_allclose(got[k], single[k].numpy(), rtol=2e-4, atol=2e-6, err_msg=f"rank {rank} {k}")
     # the pose gate uses the GLOBAL window position: view 3 (>= pose_window) keeps its deltas un-applied
     assert np.abs(ret[1]["tau3"]).max() > 0 and np.abs(ret[1]["tau1"]).max() == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE config 5's iteration on FOUR ranks: 10 views (8 window + 2 old keyframes, slam_backend.py:183-242)
+# dealt round-robin - 3 / 3 / 2 / 2 views per rank, the uneven split DESIGN.md section 6 prices.
+def _mapping_worker_uneven(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from monogs_amd.parallel import FlatGradBucket
+    gauss, views = _mapping_fixture(10)
+    local = [v for v in views if v.uid % world == rank]
+    bucket = FlatGradBucket([gauss._xyz, gauss._features_dc, gauss._opacity, gauss._scaling, gauss._rotation])
+    st = _run_mapping(gauss, local, [v.uid for v in local], bucket, pose_window=5)
+    st["n_local"] = torch.tensor(len(local))
+    ret[rank] = {k: v.numpy() for k, v in st.items()}
+    dist.destroy_process_group()
+
+
+def test_sharded_mapping_step_matches_single_process_world4_uneven_split():
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    gauss, views = _mapping_fixture(10)
+    single = _run_mapping(gauss, views, None, None, pose_window=5)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + ((os.getpid() + 291) % 500)
+    mp.spawn(_mapping_worker_uneven, args=(4, port, ret), nprocs=4, join=True)
+    assert [int(ret[r]["n_local"]) for r in range(4)] == [3, 3, 2, 2]
+    for rank in range(4):
+        got = ret[rank]
+        # replicated state: every rank holds the same stepped map and the same summed statistics
+        for k in ("xyz", "scaling", "opacity", "rot", "fdc", "grad_norm", "denom", "radii"):
+            np.testing.assert_allclose(got[k], single[k].numpy(), rtol=3e-4, atol=3e-6, err_msg=f"rank {rank} {k}")
+        # per-view state lives on the owning rank
+        for uid in range(10):
+            if uid % 4 == rank:
+                for k in (f"T{uid}", f"a{uid}", f"tau{uid}"):
+                    np.testing.assert_allclose(got[k], single[k].numpy(), rtol=3e-4, atol=3e-6, err_msg=f"rank {rank} {k}")
+    # update_pose is gated by the GLOBAL window position (slam_backend.py:328-332): view 4 (rank 0's second
+    # view, < pose_window = 5) was applied, view 5 (rank 1's second) keeps its stepped deltas
+    assert np.abs(ret[0]["tau4"]).max() == 0 and np.abs(ret[1]["tau5"]).max() > 0
+    # keyframe 0 is never moved (update_pose skips uid 0, slam_backend.py:328-332)
+    from monogs_amd.parallel import view_pose
+    np.testing.assert_array_equal(ret[0]["T0"], view_pose(0).numpy())

@@ -21,7 +21,8 @@ def _dev():
     return torch.device("cuda", 0)
 
 
-def _window_fixture(N=4000, W=160, H=120, n_views=3, seed=11, dev=None, rgbd=False, intrinsics=None):
+def _window_fixture(N=4000, W=160, H=120, n_views=3, seed=11, dev=None, rgbd=False, intrinsics=None, sh_degree=0,
+                    active_degree=None):
     from monogs_amd import synthetic as S
     from monogs_amd.gaussian_model import GaussianModel
     from monogs_amd.parallel import view_pose
@@ -30,11 +31,15 @@ def _window_fixture(N=4000, W=160, H=120, n_views=3, seed=11, dev=None, rgbd=Fal
     cam = sc.cam
     fovx, fovy = 2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy)
     g = torch.Generator().manual_seed(seed + 1)
-    gm = GaussianModel(0, device=dev)
+    gm = GaussianModel(sh_degree, device=dev)
     import torch.nn as nn
     gm._xyz = nn.Parameter(sc.means3D.to(dev).contiguous())
     gm._features_dc = nn.Parameter(sc.features_dc.to(dev).contiguous())
-    gm._features_rest = nn.Parameter(torch.zeros(N, 0, 3, device=dev))
+    K = (sh_degree + 1) ** 2
+    # stored SH bands above the constant one (K > 1): cat(features_dc, features_rest) in mgs_map_activate, the
+    # general-degree instantiation of the preprocess backward and grad_features_rest
+    gm._features_rest = nn.Parameter((0.3 * torch.randn(N, K - 1, 3, generator=g)).to(dev).contiguous())
+    gm.active_sh_degree = sh_degree if active_degree is None else active_degree
     gm._scaling = nn.Parameter(sc.log_scales.to(dev).contiguous())
     # un-normalised quaternions: the chain through normalize() is part of what is tested
     gm._rotation = nn.Parameter((sc.rot * (0.5 + torch.rand(N, 1, generator=g))).to(dev).contiguous())
@@ -65,21 +70,26 @@ def _oracle_window_gradients(sc, gm, views, rgbd=False, alpha=0.95):
     from monogs_amd import synthetic as S
     from oracle import torch_raster as O
     leaves = {k: getattr(gm, k).detach().cpu().clone().requires_grad_() for k in
-              ("_xyz", "_features_dc", "_scaling", "_rotation", "_opacity")}
+              ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")}
+    deg = int(gm.active_sh_degree)
     N = leaves["_xyz"].shape[0]
     total = 0.0
     per_view, stats = [], dict(gradnorm=torch.zeros(N), denom=torch.zeros(N), radii=torch.zeros(N, dtype=torch.int32),
                                vis=[])
     for v in views:
         cam = S.make_camera(v.image_width, v.image_height, v.T.detach().cpu(), intrinsics=(v.fx, v.fy, v.cx, v.cy))
-        st = oracle_settings(cam, torch.zeros(3))
+        # campos: the reference's camera_center IS world_view_transform (camera_utils.py:106-108), i.e. the
+        # extension reads the first three floats of the view matrix; the native mapper passes the same pointer
+        # and oracle_settings defaults to it
+        st = oracle_settings(cam, torch.zeros(3), deg=deg)
         theta = torch.zeros(3, requires_grad=True)
         rho = torch.zeros(3, requires_grad=True)
         a = v.exposure_a.detach().cpu().clone().requires_grad_()
         b = v.exposure_b.detach().cpu().clone().requires_grad_()
         m2d = torch.zeros(N, 3, requires_grad=True)
         img, radii, dep, opa, nt, _ = O.rasterize(
-            leaves["_xyz"], m2d, leaves["_features_dc"], None, torch.sigmoid(leaves["_opacity"]),
+            leaves["_xyz"], m2d, torch.cat((leaves["_features_dc"], leaves["_features_rest"]), dim=1), None,
+            torch.sigmoid(leaves["_opacity"]),
             torch.exp(leaves["_scaling"]), torch.nn.functional.normalize(leaves["_rotation"]), None, st, theta, rho)
         gt = v.original_image.cpu()
         mask = v.rgb_pixel_mask_mapping.cpu().float()
@@ -111,6 +121,16 @@ def test_native_window_gradients_match_the_oracle(built, rgbd):
     _check_window_against_oracle(rgbd)
 
 
+@pytest.mark.parametrize("sh_degree,active", [(1, 1), (3, 3), (2, 1), (1, 0)])
+def test_native_window_gradients_match_the_oracle_with_sh_bands(built, sh_degree, active):
+    """Mapping mode with K > 1 stored SH coefficients (sh_degree 1: K = 4; 3: K = 16): mgs_map_activate's
+    cat(features_dc, features_rest), k_preprocess_bwd<MAP, general degree> (the view-direction term of
+    dL/dxyz included) and mgs_map_accum_args.grad_features_rest, accumulated over a 3-view window, against
+    the oracle.  (2, 1) / (1, 0): stored degree above the active one (oneupSHdegree has not caught up,
+    gaussian_model.py:104-106) - the higher bands must get exactly zero."""
+    _check_window_against_oracle(False, sh_degree=sh_degree, active_degree=active)
+
+
 def test_native_window_gradients_match_the_oracle_at_the_replica_shape(built):
     """BASELINE config 5's view shape - Replica office0 calibration, 1200x680, RGB-D objective
     (configs/rgbd/replica/base_config.yaml:12,27-28; utils/slam_utils.py:243-253) - through the native
@@ -139,9 +159,18 @@ def _check_window_against_oracle(rgbd, **fixture_kw):
         mp._run_view(kf, n, accumulate=n > 0, add_reg=n == 0, in_window=True)
     torch.cuda.synchronize()
     assert mp.check_capacity()
-    for name, attr in (("xyz", "_xyz"), ("f_dc", "_features_dc"), ("opacity", "_opacity"), ("scaling", "_scaling"),
-                       ("rotation", "_rotation")):
+    names = [("xyz", "_xyz"), ("f_dc", "_features_dc"), ("opacity", "_opacity"), ("scaling", "_scaling"),
+             ("rotation", "_rotation")]
+    if gm._features_rest.shape[1] > 0:
+        names.append(("f_rest", "_features_rest"))
+    for name, attr in names:
         got = mp._section(name).view_as(getattr(gm, attr)).cpu()
+        if attr == "_features_rest":
+            act = (int(gm.active_sh_degree) + 1) ** 2 - 1          # bands above the active degree: exactly zero
+            assert float(got[:, act:].abs().max()) == 0.0 if act < got.shape[1] else True
+            assert float(want[attr][:, act:].abs().max()) == 0.0 if act < got.shape[1] else True
+            if act == 0:
+                continue
         err = rel_err(got, want[attr])
         assert err < 2e-3, f"{attr}: window-summed gradient rel err {err}"
     assert rel_err(mp._section("gradnorm").cpu(), stats["gradnorm"]) < 2e-3

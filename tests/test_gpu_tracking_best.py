@@ -127,20 +127,61 @@ def test_native_two_phase_run_matches_the_python_loop(built):
         return sketch_args_from_buckets(bucket, w, H, W, stack, sketch)
 
     vp, _ = _frame(view, gauss, dev, 3, T0)
+    trace_p = []
     pkg, best_p, it_p, n_p = track_frame(vp, gauss, bg, first_order_iters=fo, second_order_iters=so, config=cfg,
-                                         stack_dim=stack, sketch_dim=sketch, fsa_fn=fsa_fn)
-    # the second order may converge (|x| < 1e-5) before its budget: the Python loop then stops at once, the
-    # native run at its next read-back of the sticky flag (the iterations in between change nothing)
-    # Which iteration's step first falls below 1e-5 is a matter of the two paths' rounding: one iteration either way.
-    assert fo < n_p <= fo + so and fo < n <= fo + so and n >= n_p - 1
-    print('best iterate', it_p, 'of', fo, '+', so, 'L1', best_p)
-    # (in the converged second-order tail neighbouring iterations' L1 differ by rounding only: there the two
-    # paths may name neighbours; the best LOSS and the final pose are compared below)
+                                         stack_dim=stack, sketch_dim=sketch, fsa_fn=fsa_fn, trace=trace_p)
+    # The same frame again through the native iterations ONE AT A TIME, reading the device-side trace after each
+    # (best[21] = L1 of the iteration's render, best[22] = |step|): the sequence run() enqueues, with
+    # check_every = 1.
+    vt, _ = _frame(view, gauss, dev, 6, T0)
+    trt = NativeTracker(vt, gauss, bg, lr_rot=BIG_LR["cam_rot_delta"], lr_trans=BIG_LR["cam_trans_delta"])
+    trt.enable_second_order(stack_dim=stack, sketch_dim=sketch, seed=seed)
+    trt.reset_frame()
+    trace_n = []
+    for _ in range(fo):
+        conv = bool(trt.step().item())
+        trace_n.append((float(trt.last_l1), float(trt.last_step_norm), conv))
+        assert not conv                                   # the overshooting first order never converges here
+    trt.assign_best()
+    for _ in range(so):
+        st = trt.step_second_order()
+        conv = float(st[3]) != 0.0
+        trace_n.append((float(trt.last_l1), float(trt.last_step_norm), conv))
+        if conv:
+            break
+    assert trt.check_capacity()
+    # (a) Per-iteration agreement of the two paths up to the first converged iteration of either: the L1 criterion
+    # to 1e-4 relative (+ 1e-6 of the initial residual: at the optimum what is left of it IS rounding - the target is
+    # a render of the same map), the step norms to 1e-3 relative (+ 1e-7 absolute: the converged threshold is 1e-5).
+    first_conv = min(next((i for i, t in enumerate(tr) if t[2]), len(tr)) for tr in (trace_p, trace_n))
+    upto = min(first_conv + 1, len(trace_p), len(trace_n))
+    assert upto > fo                                      # the comparison reaches into the second-order phase
+    for i in range(upto):
+        lp, sp, _ = trace_p[i]
+        ln, sn, _ = trace_n[i]
+        assert abs(lp - ln) <= 1e-4 * lp + 1e-6 * l1s[0], (i, lp, ln)
+        assert abs(sp - sn) <= 1e-3 * sp + 1e-7, (i, sp, sn)
+    # (b) How many iterations each path takes: the Python loop stops at its first converged iteration, the traced
+    # native one too; they may differ only where the step norm sits at the threshold (1e-5) to within the
+    # agreement measured in (a).
+    if len(trace_p) != len(trace_n):
+        i = min(len(trace_p), len(trace_n)) - 1
+        assert abs(trace_p[i][1] - 1e-5) <= 1e-3 * 1e-5 + 1e-7 or abs(trace_n[i][1] - 1e-5) <= 1e-3 * 1e-5 + 1e-7, \
+            (trace_p[i], trace_n[i])
+    # run() (read-back every 4 iterations; the iterations enqueued after the sticky flag change nothing) ends where
+    # the one-at-a-time sequence ends
+    assert fo < n_p <= fo + so and fo < n <= fo + so and n >= len(trace_n)
+    assert torch.allclose(vn.T, vt.T, atol=1e-5) and abs(float(trk.best_loss) - float(trt.best_loss)) <= 1e-4 * float(trt.best_loss)
+    # (c) The best iterate: the same index, unless the two paths' L1 of the two candidate iterations agree to 1e-6
+    # relative with EACH OTHER (a tie that rounding decides) - the slack is tied to that measured quantity.
     bi = trk.best_iteration()
-    assert bi == it_p or (min(bi, it_p) >= fo and abs(bi - it_p) <= 1), (bi, it_p)
-    # at the optimum the residual is ~1e-4 of the initial one (the target is a render of the same map): the
-    # two paths' rounding shows in what is left, so the tolerance is tied to the initial residual as well
-    assert abs(trk.best_loss.item() - best_p) <= 5e-3 * best_p + 1e-4 * l1s[0]
+    print('best iterate', it_p, bi, 'of', fo, '+', so, 'L1', best_p, [t[0] for t in trace_p[fo:]], [t[0] for t in trace_n[fo:]])
+    assert bi == trt.best_iteration()
+    if bi != it_p:
+        assert max(bi, it_p) < upto
+        cand = [trace_p[bi][0], trace_p[it_p][0], trace_n[bi][0], trace_n[it_p][0]]
+        assert max(cand) - min(cand) <= 1e-6 * max(cand) + 1e-6 * l1s[0], (bi, it_p, cand)
+    assert abs(trk.best_loss.item() - best_p) <= 1e-4 * best_p + 1e-6 * l1s[0]
     assert torch.allclose(vn.T, vp.T, atol=5e-4)
     assert torch.allclose(vn.exposure_a, vp.exposure_a, atol=5e-4)
     err0 = (T0 - torch.eye(4)).abs().max().item()
