@@ -76,6 +76,21 @@ def parse(argv=None):
     return args
 
 
+def csrc_tree_hash():
+    """sha256 over the kernel sources (monogs_amd/csrc/*, include/monogs_raster.h; names and contents, sorted):
+    what profiles/pmc_traffic.json was collected on must be what this run executes, or `roofline.traffic`
+    is null (profiles/collect.sh stores the hash at collection)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "monogs_amd", "csrc")
+    files = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".h"))]
+    files.append(os.path.join(ROOT, "include", "monogs_raster.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def spawn_ranks(args, argv):
     """`bench.py --gpus N` without a launcher: start N ranks as a child torch.distributed.run.
     Nothing in THIS process has initialised the GPU (no torch.cuda call so far), and the program
@@ -374,14 +389,22 @@ def main(argv=None):
         timed(k, timed_exchange=True)
         ex_ms = sum(a.elapsed_time(b) for a, b in ex_events) / max(1, len(ex_events))
         gathered = [None] * world
+        props = torch.cuda.get_device_properties(dev)
+        bus = "%04x:%02x:%02x" % tuple(getattr(props, k, 0) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
         dist.all_gather_object(gathered, {"rank": rank, "compute_ms": round(t_compute, 4),
                                           "exchange_ms": round(ex_ms, 4), "pairs_D": D,
-                                          "device": torch.cuda.get_device_name(dev)})
+                                          "device": torch.cuda.get_device_name(dev), "pci_bus": bus,
+                                          "uuid": str(getattr(props, "uuid", "")), "local_rank": local_rank,
+                                          "host": socket.gethostname()})
         flat_bytes = bucket.flat.numel() * 4 + bucket.radii.numel() * 4
         backend_name = "rccl" if backend == "nccl" else backend
         if shared_gpu:
             backend_name += " (host-staged rehearsal, ranks share a GPU: not a performance number)"
         multi = {"backend": backend_name,
+                 # proof that N ranks ran on N distinct GPUs: what the process group reports and each rank's device
+                 "ranks_seen": dist.get_world_size(),
+                 "devices_per_rank": [f"{g['device']} @ {g['pci_bus']} (cuda:{g['local_rank']}, {g['host']})" for g in gathered],
+                 "distinct_gpus": len({(g["host"], g["pci_bus"], g["uuid"]) for g in gathered}),
                  "exchange_ms": round(max(g["exchange_ms"] for g in gathered), 4),
                  "compute_ms_per_rank": [g["compute_ms"] for g in gathered],
                  "exchange_ms_per_rank": [g["exchange_ms"] for g in gathered],
@@ -418,12 +441,26 @@ def main(argv=None):
         # HBM traffic per launch from the committed PMC pass of THIS round's kernels (rocprofv3
         # cannot run inside this process; profiles/collect.sh regenerates the file); only valid
         # for the default workload it was collected on
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if (N, W, H) == (300_000, 640, 480) and os.path.exists(tpath):
-            traffic = json.load(open(tpath))["bytes_per_launch"].get(dom)
+        here = csrc_tree_hash()
+        if (N, W, H) != (300_000, 640, 480):
+            traffic_source = "none: the committed PMC pass covers the default workload only"
+        elif not os.path.exists(tpath):
+            traffic_source = "none: profiles/pmc_traffic.json absent"
+        else:
+            tj = json.load(open(tpath))
+            if tj.get("csrc_tree_hash") == here:
+                traffic = tj["bytes_per_launch"].get(dom)
+                traffic_source = (f"profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                  f"profiles/collect.sh on these kernel sources (csrc hash {here})")
+            else:
+                traffic_source = (f"none: profiles/pmc_traffic.json was collected on kernel sources "
+                                  f"{tj.get('csrc_tree_hash', '(unrecorded)')}, this run executes {here} - stale, "
+                                  "re-run profiles/collect.sh")
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0,
                     "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                    "traffic_source": traffic_source,
                     "algorithmic_bytes": alg[dom], "avg_us": kernels[dom]}
 
     # ---- single-GPU extras: sustained rate and the default autograd engine ----
@@ -517,6 +554,9 @@ def main(argv=None):
             "config": {"workload": f"{wname}: {N} Gaussians @ {W}x{H}, SH degree 0, fwd+bwd incl. "
                                    "pose Jacobian through the autograd binding",
                        "pairs_D": D, "views_per_step": world, "autograd_multithreading": bool(engine_mt),
+                       # the autograd engine mode `value` was timed in (the faster of an untimed calibration;
+                       # `value_default_engine` = PyTorch's default, what an untouched MonoGS process gets)
+                       "value_engine_mode": "default_worker_thread" if engine_mt else "calling_thread",
                        "parallelism": f"keyframe-parallel x{world}" if distributed else "single view"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels_us": kernels,
         }

@@ -185,7 +185,12 @@ typedef struct mgs_backward_args {
 #define MGS_CLAMP_GRAD_UPSTREAM 0
 #define MGS_CLAMP_GRAD_EXACT 1
   int32_t clamp_gradient_mode;
-  int32_t reserved0;
+  /* An UPPER BOUND of the forward's pair count D when the caller knows one (the autograd binding has read the
+   * exact D from the pinned slot before the backward is enqueued), 0 = none.  Sizes the grid of the blend
+   * backward: D / 32 + tiles work items instead of pair_capacity / 32 + tiles.  A value BELOW the true count
+   * loses work items - the native entry points, which cannot know D of the forward they have just enqueued,
+   * leave it 0. */
+  int32_t pair_count_bound;
 } mgs_backward_args;
 
 int32_t mgs_abi_version(void);
@@ -540,8 +545,8 @@ int32_t mgs_sketch_residual(const mgs_sketch_residual_args* args, void* stream);
  * repeat_dim (RGN.second_order.repeat_dim, configs/mono/tum/base_config.yaml:258; utils/slam_frontend.py:654-669):
  * R backward passes over ONE render, each with its own partition (key + r * golden ratio) and weights; the rows of
  * Sf / SJ are stacked ([R d] rows in the solve).  `bucket` / `weights` then hold R planes of H*W.
- * If a step of the sequence fails after the accumulators were touched, they (and the per-pixel Jacobian rows in
- * sketch_ws) are cleared before the error is returned, so scratch_kept_zero survives a failed call. */
+ * If a step of the sequence fails after the accumulators were touched, they are cleared before the error is
+ * returned, so scratch_kept_zero survives a failed call. */
 typedef struct mgs_tracking_so_args {
   mgs_tracking_iter_args base;
   int32_t stack_dim, sketch_dim;

@@ -68,7 +68,7 @@ class BackwardArgs(C.Structure):
         + [("sketch_mode", C.c_int32), ("sketch_dim", C.c_int32), ("stack_dim", C.c_int32),
            ("sketch_indices", _fp), ("grad_sketch_dtau", _fp), ("sketch_ws", _fp),
            ("sketch_bucket_flat", _fp), ("map_accum", C.POINTER(MapAccumArgs)),
-           ("clamp_gradient_mode", C.c_int32), ("reserved0", C.c_int32)])
+           ("clamp_gradient_mode", C.c_int32), ("pair_count_bound", C.c_int32)])
 
 
 class PoseAdamArgs(C.Structure):

@@ -102,7 +102,10 @@ __device__ __forceinline__ float min_f32(float a, float b) { float r; asm("v_min
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 template <bool SKETCH, bool JONLY = false, bool POSE = false>
-__global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(KP P, KB B) {
+#ifndef MGS_BWD_WAVES
+#define MGS_BWD_WAVES 6
+#endif
+__global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : MGS_BWD_WAVES) void k_blend_bwd(KP P, KB B) {
   MGS_BSTAMP;
   static_assert(SKETCH || !JONLY, "JONLY is a sketch-mode variant");
   static_assert(!(SKETCH && POSE), "POSE is a plain-mode variant");
@@ -120,34 +123,41 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
   MGS_BORDER(item_first, SKETCH);
   if (item_first < 0) return;
   if (item_first >= n_items) return;
+  // (The grid covers every work item: capacity / kItem + T of them, or pair_count_bound / kItem + T when the caller
+  // knows the forward's pair count.  A grid-stride loop over the items - which would make ANY grid safe, e.g. one
+  // sized from the previous view's count - cost this kernel 8 VGPRs and its seventh wave per SIMD: not shipped.)
   // sketch mode: per-pixel pose-Jacobian rows, as pairs (tau 0,1) (2,3) (4,5), of the tile in hand
   v2f J2[SKETCH ? 4 : 1][3];
 #pragma unroll
   for (int q = 0; q < (SKETCH ? 4 : 1); q++)
 #pragma unroll
     for (int t = 0; t < 3; t++) J2[q][t] = v2f{0.f, 0.f};
-  unsigned int jq_mask = 0u;       // quadrants whose rows received a contribution
-  int jtile = -1;
+  unsigned int jq_mask = 0u;       // quadrants in which this lane's rows received a contribution
+  int jtile = -1, jitem = 0;       // the tile in hand and the first item of this wave's run in it (= its slab)
   auto flush_jacobian = [&]() {
     if constexpr (SKETCH) {
       if (jtile < 0) return;
-      // pixel rows of different items of a tile meet in pix_jac: float atomics, planar
-      // [6][H*W] so a wave instruction covers 8-pixel runs of contiguous addresses
-      const int fx = (jtile % P.grid_x) * kTile + (lane & 7), fy = (jtile / P.grid_x) * kTile + (lane >> 3);
-      const size_t HWf = (size_t)P.W * P.H;
+      // This run's rows as one slab, float[6][256] in quadrant-major order (entry t * 256 + 64 q + lane): plain
+      // 256-B stores, only the quadrants that received something; the mask word says which.  EVERY run start of
+      // the forward's item structure gets its word from this launch (also an all-zero one), so the reader never
+      // sees a stale word and nothing has to be cleared between launches.
+      // (jq_mask is per lane - a lane sets a bit only where it blended something: the wave's union decides what
+      // is stored, and every lane stores its row, zeros included)
+      unsigned int wmask = 0u;
+#pragma unroll
+      for (int q = 0; q < 4; q++) wmask |= (__ballot((jq_mask >> q) & 1u) != 0ull ? 1u : 0u) << q;
+      float* slab = B.slabs + (size_t)jitem * (6 * 256) + lane;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        if ((jq_mask >> q) & 1u) {                  // else: nothing to add, the items never reached this quadrant
-          const int px = fx + 8 * (q & 1), py = fy + 8 * (q >> 1);
-          if (px < P.W && py < P.H) {
-            const size_t pix = (size_t)py * P.W + px;
+        if ((wmask >> q) & 1u) {                    // wave-uniform
 #pragma unroll
-            for (int t = 0; t < 6; t++) atomicAdd(&B.pix_jac[(size_t)t * HWf + pix], (t & 1) ? J2[q][t >> 1].y : J2[q][t >> 1].x);
-          }
+          for (int t = 0; t < 6; t++) slab[t * 256 + 64 * q] = (t & 1) ? J2[q][t >> 1].y : J2[q][t >> 1].x;
         }
 #pragma unroll
         for (int t = 0; t < 3; t++) J2[q][t] = v2f{0.f, 0.f};
       }
+      jq_mask = wmask;
+      if (lane == 0) B.slab_mask[jitem] = jq_mask;
       jq_mask = 0u;
     }
   };
@@ -161,10 +171,10 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
   const int tile = sr.x, k0 = sr.y, nb = sr.z, base = sr.w;
   MGS_BFINE(0, "s_waitcnt lgkmcnt(0)");
   MGS_BITEM(item, base);
-  if (nb <= 0) continue;
   if constexpr (SKETCH) {
-    if (tile != jtile) { flush_jacobian(); jtile = tile; }
+    if (tile != jtile) { flush_jacobian(); jtile = tile; jitem = item; }
   }
+  if (nb <= 0) continue;
   __builtin_assume(nb <= kItem);
   const int tx = tile % P.grid_x, ty = tile / P.grid_x;
   // Pixel q of this lane lies in QUADRANT q of the tile: (qx + 8 (q & 1), qy + 8 (q >> 1)).
@@ -217,12 +227,25 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
     int2 dl[4];
     float4 tc[4];
     bool in_img[4];
+    // A quadrant that is saturated in front of this item is masked below anyway: it loads a LIVE quadrant's lines
+    // in its place (wave-uniform select of the quadrant index), so that the dead quadrant's checkpoint, per-pixel
+    // state and gradients are not fetched from HBM (round 4: FETCH_SIZE 116.4 -> 110.6 MB per launch, same time).
+    int qsel[4];
+    {
+      int qlive = 0;
+#pragma unroll
+      for (int q = 3; q >= 0; q--) if (qlast[q] > base) qlive = q;
+#pragma unroll
+      for (int q = 0; q < 4; q++) qsel[q] = qlast[q] > base ? q : qlive;
+    }
+#define MGS_QS(q) qsel[q]
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int px = qx + 8 * (q & 1), py = qy + 8 * (q >> 1);
       in_img[q] = px < P.W && py < P.H;
-      const size_t pix = (size_t)min(py, P.H - 1) * P.W + min(px, P.W - 1);
-      const size_t qi = (size_t)tile * 256 + 64 * q + lane;     // quadrant-major: coalesced
+      const int pxl = qx + 8 * (MGS_QS(q) & 1), pyl = qy + 8 * (MGS_QS(q) >> 1);
+      const size_t pix = (size_t)min(pyl, P.H - 1) * P.W + min(pxl, P.W - 1);
+      const size_t qi = (size_t)tile * 256 + 64 * MGS_QS(q) + lane;     // quadrant-major: coalesced
       dl[q] = P.final_DL[qi];
       g0[q] = B.grad_color[pix]; g1[q] = B.grad_color[HW + pix]; g2[q] = B.grad_color[2 * HW + pix];
       gd[q] = B.grad_depth ? B.grad_depth[pix] : 0.f;
@@ -235,11 +258,12 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
     if (ck) {
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const int p = 64 * q + lane;
+        const int p = 64 * MGS_QS(q) + lane;
         k4[q] = reinterpret_cast<const float4*>(ck)[p];
         k3[q] = ck[1024 + p];
       }
     }
+#undef MGS_QS
     MGS_BFINE(2, "s_waitcnt vmcnt(0)");
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -344,7 +368,7 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
           R89 = __builtin_elementwise_fma(ww, G2d[q], R89);
         }
         if constexpr (SKETCH) {
-          jq_mask |= 1u << q;      // wave-uniform: this quadrant's rows are non-zero
+          jq_mask |= 1u << q;      // this lane's row of the quadrant is non-zero
           // J_t += W (c0 dx + c1 dy + c2 dx^2 + c3 dx dy + c4 dy^2) + (w dL/dD) c5 for the six tau
           // components: the splat's 36 coefficients are staged in LDS in feature-major order, so two
           // tau components share one packed FMA (18 instead of 36 per quadrant)
@@ -534,42 +558,55 @@ __global__ __launch_bounds__(kPreBlock) void k_sketch_prep(KP P, KB B) {
   }
 }
 
-constexpr int kBucketBlocks = 128;
+constexpr int kBucketBlocks = 256;      // persistent workgroups (one per CU), four tiles in hand each
+constexpr int kBucketThreads = 1024;
 
-__global__ __launch_bounds__(256) void k_sketch_bucket(KP P, KB B) {
+// Per tile: per-pixel rows = sum of the tile's slabs (k_blend_bwd<SKETCH> left one per run of kSketchReps items:
+// at the tile's first item and at every multiple of kSketchReps inside it), then the pixel's bucket(s) in an
+// LDS-privatised table, flushed with one float atomic per entry and workgroup.  A 256-thread quarter of the
+// workgroup holds a tile in the quadrant-major order of the slabs (thread = 64 q + lane): coalesced 1-KB loads.
+__global__ __launch_bounds__(kBucketThreads) void k_sketch_bucket(KP P, KB B) {
   extern __shared__ float s_acc[];    // stack * sketch * 6
   const int nacc = B.stack_dim * B.sketch_dim * 6;
   const size_t HW = (size_t)P.W * P.H;
-  for (int i = threadIdx.x; i < nacc; i += 256) s_acc[i] = 0.f;
+  for (int i = threadIdx.x; i < nacc; i += kBucketThreads) s_acc[i] = 0.f;
   __syncthreads();
-  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < HW; p += (size_t)gridDim.x * 256) {
-    float J[6];
+  const int sub = threadIdx.x >> 8, tid = threadIdx.x & 255, q = tid >> 6, lane = tid & 63;
+  for (int tile = blockIdx.x * 4 + sub; tile < P.T; tile += gridDim.x * 4) {
+    const int a = P.seg_offset[tile], b = min(P.seg_offset[tile + 1], P.max_segs);
+    float J[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = a; i < b; i = (i / kSketchReps + 1) * kSketchReps) {       // wave-uniform
+      const unsigned int m = B.slab_mask[i];
+      if ((m >> q) & 1u) {
+        const float* slab = B.slabs + (size_t)i * (6 * 256) + tid;
 #pragma unroll
-    for (int t = 0; t < 6; t++) J[t] = B.pix_jac[(size_t)t * HW + p];
-    if (B.scratch_kept_zero) {   // this kernel is the rows' only consumer: leave them zero for the next backward
-#pragma unroll
-      for (int t = 0; t < 6; t++) B.pix_jac[(size_t)t * HW + p] = 0.f;
+        for (int t = 0; t < 6; t++) J[t] += slab[t * 256];
+      }
     }
+    const int px = (tile % P.grid_x) * kTile + (lane & 7) + 8 * (q & 1);
+    const int py = (tile / P.grid_x) * kTile + (lane >> 3) + 8 * (q >> 1);
+    if (px >= P.W || py >= P.H) continue;
+    const size_t p = (size_t)py * P.W + px;
     if (B.sketch_flat) {      // one bucket per pixel
-      const int b = B.sketch_flat[p];
-      if (b >= 0 && b < B.stack_dim * B.sketch_dim) {
-        float* a = &s_acc[b * 6];
+      const int bk = B.sketch_flat[p];
+      if (bk >= 0 && bk < B.stack_dim * B.sketch_dim) {
+        float* acc = &s_acc[bk * 6];
 #pragma unroll
-        for (int t = 0; t < 6; t++) atomicAdd(&a[t], J[t]);
+        for (int t = 0; t < 6; t++) atomicAdd(&acc[t], J[t]);
       }
     } else {
-      for (int s = 0; s < B.stack_dim; s++) {
-        const int k = B.sketch_idx[(size_t)s * HW + p];
+      for (int st = 0; st < B.stack_dim; st++) {
+        const int k = B.sketch_idx[(size_t)st * HW + p];
         if (k >= 0 && k < B.sketch_dim) {
-          float* a = &s_acc[(s * B.sketch_dim + k) * 6];
+          float* acc = &s_acc[(st * B.sketch_dim + k) * 6];
 #pragma unroll
-          for (int t = 0; t < 6; t++) atomicAdd(&a[t], J[t]);
+          for (int t = 0; t < 6; t++) atomicAdd(&acc[t], J[t]);
         }
       }
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < nacc; i += 256) {
+  for (int i = threadIdx.x; i < nacc; i += kBucketThreads) {
     const float v = s_acc[i];
     if (v != 0.f) atomicAdd(&B.g_sketch[i], v);
   }
@@ -866,28 +903,28 @@ int launch_visibility(const int* n_touched, unsigned char* vis, int n, hipStream
 int launch_backward(const KP& P, const KB& B, hipStream_t st, bool skip_tau_reduce) {
   // k_blend_bwd stores the pair records through a raw buffer descriptor of kPairBufferExtent bytes (53 M pairs)
   if ((unsigned long long)max(P.cap, 0) * (kPairStride * 4) > kPairBufferExtent) return MGS_ERR_UNSUPPORTED;
+  // work items to launch for: a tile holds at most one partly filled item more than its pairs / kItem
+  const int items = B.pair_bound > 0 ? (int)min((long long)P.max_segs, (long long)B.pair_bound / kItem + P.T) : P.max_segs;
   if (B.sketch_mode != 0) {
     const size_t HW = (size_t)P.W * P.H;
     const size_t nacc = (size_t)B.stack_dim * B.sketch_dim * 6;
     if (nacc * sizeof(float) > 64 * 1024) return MGS_ERR_UNSUPPORTED;
-    if (!B.scratch_kept_zero &&
-        (!hip_ok("memset(per-pixel Jacobian rows)", hipMemsetAsync(B.pix_jac, 0, HW * 6 * sizeof(float), st)) ||
-         !hip_ok("memset(sketched Jacobian)", hipMemsetAsync(B.g_sketch, 0, nacc * sizeof(float), st)))) {
+    if (!B.scratch_kept_zero && !hip_ok("memset(sketched Jacobian)", hipMemsetAsync(B.g_sketch, 0, nacc * sizeof(float), st))) {
       launches_ok();      // (reported above; the per-thread slot is cleared for the next entry point)
       return MGS_ERR_LAUNCH;
     }
     launch("sketch_prep", k_sketch_prep, dim3((P.N + kPreBlock - 1) / kPreBlock), dim3(kPreBlock), st, P, B);
     if (B.sketch_only)
-      launch("blend_bwd_sketch", k_blend_bwd<true, true>, dim3(grid_pad((P.max_segs + kSketchReps - 1) / kSketchReps, kBwdChunk)), dim3(64), st, P, B);
+      launch("blend_bwd_sketch", k_blend_bwd<true, true>, dim3(grid_pad((items + kSketchReps - 1) / kSketchReps, kBwdChunk)), dim3(64), st, P, B);
     else
-      launch("blend_bwd_sketch", k_blend_bwd<true, false>, dim3(grid_pad((P.max_segs + kSketchReps - 1) / kSketchReps, kBwdChunk)), dim3(64), st, P, B);
-    launch_smem("sketch_bucket", k_sketch_bucket, dim3(kBucketBlocks), dim3(256), nacc * sizeof(float), st, P, B);
+      launch("blend_bwd_sketch", k_blend_bwd<true, false>, dim3(grid_pad((items + kSketchReps - 1) / kSketchReps, kBwdChunk)), dim3(64), st, P, B);
+    launch_smem("sketch_bucket", k_sketch_bucket, dim3(kBucketBlocks), dim3(kBucketThreads), nacc * sizeof(float), st, P, B);
     if (B.sketch_only) return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
   } else {
     if (B.g_means3D || B.map.on)
-      launch("blend_bwd", k_blend_bwd<false>, dim3(grid_pad(P.max_segs, kBwdChunk)), dim3(64), st, P, B);
+      launch("blend_bwd", k_blend_bwd<false>, dim3(grid_pad(items, kBwdChunk)), dim3(64), st, P, B);
     else   // pose-only (tracking)
-      launch("blend_bwd", k_blend_bwd<false, false, true>, dim3(grid_pad(P.max_segs, kBwdChunk)), dim3(64), st, P, B);
+      launch("blend_bwd", k_blend_bwd<false, false, true>, dim3(grid_pad(items, kBwdChunk)), dim3(64), st, P, B);
   }
   const int npre = (P.N + kPreBlock - 1) / kPreBlock;
   if (B.map.on && P.deg == 0) launch("preprocess_bwd_map", k_preprocess_bwd<true, true>, dim3(npre), dim3(kPreBlock), st, P, B);

@@ -213,13 +213,15 @@ static int32_t raster_backward_impl(const mgs_backward_args* args, void* stream,
   B.g_colors = args->grad_colors; B.g_opac = args->grad_opacities;
   B.g_scales = args->grad_scales; B.g_rots = args->grad_rotations; B.g_cov = args->grad_cov3D;
   B.g_tau = args->grad_tau;
+  B.pair_bound = args->pair_count_bound > 0 ? args->pair_count_bound : 0;
   B.sketch_mode = args->sketch_mode; B.sketch_dim = args->sketch_dim; B.stack_dim = args->stack_dim;
   B.sketch_only = (sketch_only && args->sketch_mode != 0) ? 1 : 0;
   B.scratch_kept_zero = (scratch_kept_zero && args->sketch_mode != 0) ? 1 : 0;
   B.sketch_idx = args->sketch_indices; B.g_sketch = args->grad_sketch_dtau;
   B.sketch_flat = args->sketch_indices ? nullptr : args->sketch_bucket_flat;
   char* sw = (char*)args->sketch_ws;
-  B.pix_jac = sw ? (float*)(sw + L.pix_jac) : nullptr;
+  B.slabs = sw ? (float*)(sw + L.slabs) : nullptr;
+  B.slab_mask = sw ? (unsigned int*)(sw + L.slab_mask) : nullptr;
   B.splat_jac = sw ? (float*)(sw + L.splat_jac) : nullptr;
   memset(&B.map, 0, sizeof(B.map));
   if (args->map_accum) {
@@ -402,13 +404,10 @@ int32_t mgs_tracking_iteration_second_order(const mgs_tracking_so_args* args, vo
   }
   // From here on the accumulators may hold partial sums.  In kept-zero mode only the LAST kernels of the sequence
   // restore the zeros, so a failure in between (bad argument, unsupported size, a failed launch) must not leave
-  // them dirty for the next call: clear them - and the per-pixel Jacobian rows - before returning the error.
-  const Layout lay = make_layout(b.fwd.shape);
+  // them dirty for the next call: clear them before returning the error (the backward's own scratch - slabs and
+  // their masks - is rewritten completely by every launch).
   auto fail = [&](int32_t code) {
-    if (kept) {
-      (void)hipMemsetAsync(args->accum, 0, sizeof(float) * (9 * rows + 4), st);
-      (void)hipMemsetAsync(static_cast<char*>(args->sketch_ws) + lay.pix_jac, 0, sizeof(float) * 6 * (size_t)HW, st);
-    }
+    if (kept) (void)hipMemsetAsync(args->accum, 0, sizeof(float) * (9 * rows + 4), st);
     return code;
   };
   // `repeat_dim` backward passes over ONE render (utils/slam_frontend.py:654-669): repeat r draws its own

@@ -85,14 +85,22 @@ struct KB {   // backward extras
   float* pair_grad;        // cap x kPairStride floats: the ten raw pixel sums of a pair at its slot
   float* tau_partial;      // nblocks x 6
   float *g_means3D, *g_means2D, *g_colors, *g_opac, *g_scales, *g_rots, *g_cov, *g_tau;
+  int pair_bound;           // upper bound of the forward's pair count if the caller knows one (sizes the blend grid), else 0
   int sketch_mode, sketch_dim, stack_dim;
   int sketch_only;          // sketch mode: produce grad_sketch_dtau only (no per-splat sums, no grad_tau)
-  int scratch_kept_zero;    // sketch mode: pix_jac and g_sketch are zero on entry and their consumers restore the
-                            // zeros (native second-order iteration: no hipMemsetAsync launches per iteration)
+  int scratch_kept_zero;    // sketch mode: g_sketch is zero on entry and its consumer restores the zeros (native
+                            // second-order iteration: no hipMemsetAsync launches per iteration)
   const int* sketch_idx;
   const int* sketch_flat;   // [H*W] stack * sketch_dim + bucket or -1 (compact alternative)
   float* g_sketch;
-  float* pix_jac;          // W*H x 6 per-pixel pose-Jacobian rows (sketch mode)
+  // Sketch mode: the per-pixel pose-Jacobian rows of a tile are the SUM over its backward items.  Every wave of
+  // k_blend_bwd<SKETCH> leaves the rows of each run of consecutive items of one tile it walked as ONE slab -
+  // float[6][256] in quadrant-major pixel order, plain coalesced stores - at the index of the run's first item, and
+  // k_sketch_bucket adds up a tile's slabs (until round 4 the rows met in a per-pixel array through float atomics:
+  // 75 MB of 32-B-segment atomics per launch bounded the kernel).  slab_mask[i] = quadrants written (every run
+  // start is written by every launch, so nothing is ever stale).
+  float* slabs;            // max_segs x 6 x 256
+  unsigned int* slab_mask; // max_segs
   float* splat_jac;        // N x 36 per-splat d(xy,conic,depth)/dtau (sketch mode)
   KM map;
 };
@@ -126,7 +134,7 @@ struct Layout {
       quad_last, seg_offset, obj_partial, counters, geom_bytes;
   uint64_t keys, payload, seg_rec, ckpt, max_segs, bins_bytes;
   uint64_t pair_grad, tau_partial, bwd_bytes;
-  uint64_t pix_jac, splat_jac, sketch_bytes;
+  uint64_t slab_mask, slabs, splat_jac, sketch_bytes;
 };
 
 constexpr int kScanBlock = 2048;   // elements per block in the pair_base scan
@@ -200,8 +208,9 @@ inline Layout make_layout(const mgs_raster_shape& s) {
   L.tau_partial = o; o = align_up(o + npre * 6 * 4);
   L.bwd_bytes = o;
   o = 0;
-  L.pix_jac = o; o = align_up(o + HW * 6 * 4);
+  L.slab_mask = o; o = align_up(o + (L.max_segs + 1) * 4);
   L.splat_jac = o; o = align_up(o + N * 36 * 4);
+  L.slabs = o; o = align_up(o + L.max_segs * 6 * 256 * 4);
   L.sketch_bytes = o;
   return L;
 }

@@ -197,6 +197,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         _capacity_hint[dev.index] = max(_round_cap(D), int(shape.pair_capacity * 0.97) // 1024 * 1024)
         last_stats.update(pairs=D, capacity=int(shape.pair_capacity), retried=retried, N=N)
 
+        ctx.pairs = D
         ctx.raster_settings = st
         ctx.prepared = prepared
         ctx.shape_tuple = (N, W, H, int(st.sh_degree), K, int(shape.pair_capacity))
@@ -286,6 +287,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         gc = _f32c(grad_color) if grad_color is not None else torch.zeros(3, H, W, device=dev)
         gd = _f32c(grad_depth) if grad_depth is not None else None
         b.grad_color, b.grad_depth = _ptr(gc), _ptr(gd)
+        b.pair_count_bound = int(ctx.pairs)       # D of this forward (read from the pinned slot): sizes the blend grid
         sketch_mode, sketch_dim, stack_dim = ctx.sketch
         g_sketch = None
         keep = []

@@ -169,8 +169,8 @@ class NativeTracker:
         self.so_bucket = torch.empty(R, HW, dtype=torch.int32, device=dev)
         self.so_weights = torch.empty(R, HW, device=dev)
         self.so_accum = torch.zeros(9 * R * d + 4, device=dev)
-        # zero-filled once: the iteration's kernels keep the accumulators and the Jacobian rows zero
-        # between calls (scratch_kept_zero), so no memset launches are needed per iteration
+        # zero-filled once: the iteration's kernels keep the accumulators zero between calls
+        # (scratch_kept_zero), so no memset launches are needed per iteration
         self.so_sketch_ws = torch.zeros(int(sizes.sketch_bytes), dtype=torch.uint8, device=dev)
         self.lm_state = torch.tensor([initial_lambda, 0.0, 0.0, 0.0], device=dev)
         self._lm_initial = self.lm_state.clone()
@@ -193,7 +193,13 @@ class NativeTracker:
         self._sync_pose_pointer()
         # pointers that _alloc_bins may have replaced since enable_second_order
         so.base.fwd.bins, so.base.bwd = self.args.fwd.bins, self.args.bwd
-        so.base.fwd.shape.pair_capacity = self.args.fwd.shape.pair_capacity
+        if so.base.fwd.shape.pair_capacity != self.args.fwd.shape.pair_capacity:
+            # the backward's sketch scratch holds one slab per potential backward item: it grows with the capacity
+            so.base.fwd.shape.pair_capacity = self.args.fwd.shape.pair_capacity
+            need = int(_cabi.workspace_sizes(so.base.fwd.shape).sketch_bytes)
+            if self.so_sketch_ws.numel() < need:
+                self.so_sketch_ws = torch.zeros(need, dtype=torch.uint8, device=self.dev)
+                so.sketch_ws = self.so_sketch_ws.data_ptr()
         so.base.adam.T = self.args.adam.T
         so.base.best = self.args.best
         so.base.camera_matrices_valid = 1 if self._matrices_fresh else 0

@@ -65,7 +65,11 @@ def bench_name(k):
 
 
 names = {k: bench_name(k) for k in traffic if bench_name(k)}
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_tree_hash  # noqa: E402  (the same hash bench.py checks before quoting these bytes)
 json.dump({"workload": "SYN-C 300000 @ 640x480",
+           "csrc_tree_hash": csrc_tree_hash(),
            "source": "profiles/collect.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
            "correction": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes: gfx950 FETCH_SIZE counts half of wide "
                          "coalesced loads (MI355X_MICROARCH.md, HBM)",
