@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include "launch.h"
 #include "raster_kernels.h"
+#include "sketch_kernels.h"
 #include "wave_reduce.h"
 #define MGS_DIAG_BACKWARD
 #include "diag_stamp.h"
@@ -105,14 +106,26 @@ template <bool SKETCH, bool JONLY = false, bool POSE = false>
 #ifndef MGS_BWD_WAVES
 #define MGS_BWD_WAVES 6
 #endif
-__global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : MGS_BWD_WAVES) void k_blend_bwd(KP P, KB B) {
+#ifndef MGS_SK_WAVES
+#define MGS_SK_WAVES 4
+#endif
+#ifndef MGS_SKF_WAVES
+#define MGS_SKF_WAVES 3
+#endif
+__global__ __launch_bounds__(64, SKETCH ? (JONLY ? MGS_SK_WAVES : MGS_SKF_WAVES) : MGS_BWD_WAVES) void k_blend_bwd(KP P, KB B) {
   MGS_BSTAMP;
   static_assert(SKETCH || !JONLY, "JONLY is a sketch-mode variant");
   static_assert(!(SKETCH && POSE), "POSE is a plain-mode variant");
   static_assert(kSeg == 64, "one staged record per lane");
   __shared__ float4 s_r0[kSeg], s_r1[kSeg];
   __shared__ float2 s_r2[kSeg];             // 2560 B of LDS in all
-  __shared__ float4 s_coef[SKETCH ? kSeg : 1][9];   // per splat: 6 features x 6 tau components
+  // per splat: 6 features x 6 tau components.  An item holds at most kItem (32) splats - half a 64-lane segment:
+  // sized for that (4.6 KB instead of 9.2 KB per wave), the staging no longer caps a CU at 13 waves (round 4).
+  __shared__ float4 s_coef[SKETCH ? kItem : 1][9];
+  // (Round 4 tried the scalar path for them - the 36 coefficients of a splat are wave-uniform: s_load_dwordx16 from
+  // the constant address space into SGPRs, v_pk_fma_f32 with scalar operands, no LDS staging: 124 -> 115 VGPRs, 106
+  // SGPRs with 4 spilled, and 176.6 -> 185.8 us: the loads cannot be issued a splat ahead (72 SGPRs) and their
+  // latency sits in the walk.  profiles/r04_backward_blend_tuning.txt.)
   // Sketch mode: a workgroup takes kSketchReps consecutive items (mostly of one tile) and adds its
   // per-pixel Jacobian rows to pix_jac once per tile instead of once per item: the atomics, not the
   // walk, bound that variant, and the 32-splat items doubled them.
@@ -516,8 +529,7 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : MGS_BWD_WAVES) void 
 //                    conic into 36 polynomial coefficients
 //   k_blend_bwd<1>   per (pixel, splat): J_p += W * poly(dx, dy) + w dL/dD * c  (6 components)
 //   k_sketch_bucket  per pixel: J_p -> LDS-privatised bucket table -> grad_sketch_dtau
-__global__ __launch_bounds__(kPreBlock) void k_sketch_prep(KP P, KB B) {
-  const int idx = blockIdx.x * kPreBlock + threadIdx.x;
+__device__ __forceinline__ void sketch_prep_gaussian(const KP& P, const KB& B, int idx) {
   if (idx >= P.N) return;
   const float4 r1 = reinterpret_cast<const float4*>(P.rec + idx)[1];
   float* out = B.splat_jac + (size_t)idx * 36;
@@ -558,7 +570,27 @@ __global__ __launch_bounds__(kPreBlock) void k_sketch_prep(KP P, KB B) {
   }
 }
 
-constexpr int kBucketBlocks = 256;      // persistent workgroups (one per CU), four tiles in hand each
+__global__ __launch_bounds__(kPreBlock) void k_sketch_prep(KP P, KB B) {
+  sketch_prep_gaussian(P, B, blockIdx.x * kPreBlock + threadIdx.x);
+}
+
+// The residual pass of the second-order tracking iteration (sketch_kernels.h: streaming + bucket atomics, latency-
+// bound, 26 us alone at 640x480) and the per-splat preparation above (VALU-bound, 24 us alone at 300 k Gaussians) do not
+// depend on each other: ONE launch, the first `res_blocks` workgroups take the pixels, the others the Gaussians, and
+// the two populations share the CUs (round 4: 50 -> ~28 us for the pair).
+static_assert(kPreBlock == kSketchThreads, "one block size for both roles");
+__global__ __launch_bounds__(kPreBlock) void k_sketch_prep_residual(KP P, KB B, mgs_sketch_residual_args A, SketchKeys K,
+                                                                    int res_blocks) {
+  extern __shared__ float s_acc[];   // residual role: [d][3]
+  __shared__ float s_red[kSketchThreads / 64];
+  if ((int)blockIdx.x < res_blocks) sketch_residual_block(A, K, s_acc, s_red, blockIdx.x, res_blocks);
+  else sketch_prep_gaussian(P, B, ((int)blockIdx.x - res_blocks) * kPreBlock + threadIdx.x);
+}
+
+#ifndef MGS_BUCKET_BLOCKS
+#define MGS_BUCKET_BLOCKS 256
+#endif
+constexpr int kBucketBlocks = MGS_BUCKET_BLOCKS;      // persistent workgroups (one per CU), four tiles in hand each
 constexpr int kBucketThreads = 1024;
 
 // Per tile: per-pixel rows = sum of the tile's slabs (k_blend_bwd<SKETCH> left one per run of kSketchReps items:
@@ -575,12 +607,17 @@ __global__ __launch_bounds__(kBucketThreads) void k_sketch_bucket(KP P, KB B) {
   for (int tile = blockIdx.x * 4 + sub; tile < P.T; tile += gridDim.x * 4) {
     const int a = P.seg_offset[tile], b = min(P.seg_offset[tile + 1], P.max_segs);
     float J[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // The loads are unconditional and the quadrant bit selects the VALUE (a quadrant the run never reached holds
+    // whatever the buffer held): no branch between the slabs, so several slabs' loads are in flight together
+    // (with a branch per slab the ~10 slabs of a tile were ten dependent round trips).
+#pragma unroll 4
     for (int i = a; i < b; i = (i / kSketchReps + 1) * kSketchReps) {       // wave-uniform
-      const unsigned int m = B.slab_mask[i];
-      if ((m >> q) & 1u) {
-        const float* slab = B.slabs + (size_t)i * (6 * 256) + tid;
+      const bool on = (B.slab_mask[i] >> q) & 1u;
+      const float* slab = B.slabs + (size_t)i * (6 * 256) + tid;
 #pragma unroll
-        for (int t = 0; t < 6; t++) J[t] += slab[t * 256];
+      for (int t = 0; t < 6; t++) {
+        const float v = slab[t * 256];
+        J[t] += on ? v : 0.f;
       }
     }
     const int px = (tile % P.grid_x) * kTile + (lane & 7) + 8 * (q & 1);
@@ -591,8 +628,12 @@ __global__ __launch_bounds__(kBucketThreads) void k_sketch_bucket(KP P, KB B) {
       const int bk = B.sketch_flat[p];
       if (bk >= 0 && bk < B.stack_dim * B.sketch_dim) {
         float* acc = &s_acc[bk * 6];
+#ifndef MGS_DIAG_BUCKET_NOLDS
 #pragma unroll
         for (int t = 0; t < 6; t++) atomicAdd(&acc[t], J[t]);
+#else
+        if (J[0] + J[1] + J[2] + J[3] + J[4] + J[5] == 12345.f) acc[0] = 1.f;
+#endif
       }
     } else {
       for (int st = 0; st < B.stack_dim; st++) {
@@ -606,10 +647,12 @@ __global__ __launch_bounds__(kBucketThreads) void k_sketch_bucket(KP P, KB B) {
     }
   }
   __syncthreads();
+#ifndef MGS_DIAG_BUCKET_NOFLUSH
   for (int i = threadIdx.x; i < nacc; i += kBucketThreads) {
     const float v = s_acc[i];
     if (v != 0.f) atomicAdd(&B.g_sketch[i], v);
   }
+#endif
 }
 
 // ---------------------------------------------------------------------------------
@@ -900,7 +943,7 @@ int launch_visibility(const int* n_touched, unsigned char* vis, int n, hipStream
 }
 
 // ---------------------------------------------------------------------------------
-int launch_backward(const KP& P, const KB& B, hipStream_t st, bool skip_tau_reduce) {
+int launch_backward(const KP& P, const KB& B, hipStream_t st, bool skip_tau_reduce, const SketchFuse* fuse) {
   // k_blend_bwd stores the pair records through a raw buffer descriptor of kPairBufferExtent bytes (53 M pairs)
   if ((unsigned long long)max(P.cap, 0) * (kPairStride * 4) > kPairBufferExtent) return MGS_ERR_UNSUPPORTED;
   // work items to launch for: a tile holds at most one partly filled item more than its pairs / kItem
@@ -913,7 +956,18 @@ int launch_backward(const KP& P, const KB& B, hipStream_t st, bool skip_tau_redu
       launches_ok();      // (reported above; the per-thread slot is cleared for the next entry point)
       return MGS_ERR_LAUNCH;
     }
-    launch("sketch_prep", k_sketch_prep, dim3((P.N + kPreBlock - 1) / kPreBlock), dim3(kPreBlock), st, P, B);
+    const int prep_blocks = (P.N + kPreBlock - 1) / kPreBlock;
+    if (fuse && fuse->residual) {      // the residual pass rides beside the preparation (or alone: later repeats)
+      const mgs_sketch_residual_args& A = *fuse->residual;
+      const size_t smem = sizeof(float) * 3 * (size_t)A.stack_dim * A.sketch_dim;
+      if (smem > 48 * 1024) return MGS_ERR_UNSUPPORTED;
+      const long long want = (A.num_pixels + kSketchThreads - 1) / kSketchThreads;
+      const int res_blocks = (int)(want < kSketchBlocks ? want : kSketchBlocks);
+      launch_smem("sketch_prep_residual", k_sketch_prep_residual, dim3(res_blocks + (fuse->skip_prep ? 0 : prep_blocks)),
+                  dim3(kPreBlock), smem, st, P, B, A, fuse->keys, res_blocks);
+    } else if (!(fuse && fuse->skip_prep)) {
+      launch("sketch_prep", k_sketch_prep, dim3(prep_blocks), dim3(kPreBlock), st, P, B);
+    }
     if (B.sketch_only)
       launch("blend_bwd_sketch", k_blend_bwd<true, true>, dim3(grid_pad((items + kSketchReps - 1) / kSketchReps, kBwdChunk)), dim3(64), st, P, B);
     else

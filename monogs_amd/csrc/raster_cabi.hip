@@ -6,6 +6,7 @@
 
 #include "launch.h"
 #include "raster_kernels.h"
+#include "sketch_kernels.h"
 
 namespace mgs {
 namespace {
@@ -28,7 +29,7 @@ void profile_push(const char* name, hipEvent_t a, hipEvent_t b) {
 namespace mgs {
 int launch_forward_project(const KP& P, hipStream_t st);
 int launch_forward_blend(const KP& P, hipStream_t st);
-int launch_backward(const KP& P, const KB& B, hipStream_t st, bool skip_tau_reduce);
+int launch_backward(const KP& P, const KB& B, hipStream_t st, bool skip_tau_reduce, const SketchFuse* fuse);
 int launch_knn(const float* pts, int n, float* out, void* scratch, hipStream_t st);
 int launch_visibility(const int* n_touched, unsigned char* vis, int n, hipStream_t st);
 uint64_t knn_scratch_bytes(int n);
@@ -175,7 +176,8 @@ int32_t mgs_raster_forward_blend(const mgs_forward_args* args, void* stream) {
 // skip_tau_reduce: the caller sums tau_partial itself (*tau_partials / *num_partials are set)
 static int32_t raster_backward_impl(const mgs_backward_args* args, void* stream, bool skip_tau_reduce,
                                     const float** tau_partials, int32_t* num_partials,
-                                    bool sketch_only = false, bool scratch_kept_zero = false) {
+                                    bool sketch_only = false, bool scratch_kept_zero = false,
+                                    const SketchFuse* fuse = nullptr) {
   if (!args) return MGS_ERR_BAD_ARGUMENT;
   KP P;
   const int rc = fill_kp(args->fwd, true, false, P);
@@ -238,7 +240,7 @@ static int32_t raster_backward_impl(const mgs_backward_args* args, void* stream,
   }
   if (tau_partials) *tau_partials = B.tau_partial;
   if (num_partials) *num_partials = (P.N + kPreBlock - 1) / kPreBlock;
-  return launch_backward(P, B, (hipStream_t)stream, skip_tau_reduce);
+  return launch_backward(P, B, (hipStream_t)stream, skip_tau_reduce, fuse);
 }
 
 int32_t mgs_raster_backward(const mgs_backward_args* args, void* stream) {
@@ -424,7 +426,13 @@ int32_t mgs_tracking_iteration_second_order(const mgs_tracking_so_args* args, vo
     Rr.l1 = r == 0 ? l1 : l1 + 1;               // the L1 criterion is the render's: counted once
     Rr.assign = 1;                              // the bucket partition is drawn inside the residual pass
     Rr.assign_key = args->key + 0x9E3779B97F4A7C15ull * (uint64_t)r;
-    if ((rc = mgs_sketch_residual(&Rr, stream)) != MGS_OK) return fail(rc);
+    // the residual pass runs in ONE launch with the per-splat Jacobian preparation of the backward (first repeat;
+    // the preparation depends on the camera alone, the later repeats reuse it)
+    SketchFuse fuse;
+    fuse.residual = &Rr; fuse.skip_prep = r > 0 ? 1 : 0;
+    if (!Rr.gt || !Rr.exposure_a || !Rr.exposure_b || !sketch_keys(HW, args->stack_dim, args->sketch_dim, Rr.assign_key, fuse.keys))
+      return fail(MGS_ERR_BAD_ARGUMENT);
+    fuse.keys.on = 1;
     mgs_backward_args B;
     memset(&B, 0, sizeof(B));
     B.fwd = b.fwd; B.grad_color = b.grad_image; B.bwd = b.bwd; B.grad_tau = b.grad_tau;
@@ -433,7 +441,7 @@ int32_t mgs_tracking_iteration_second_order(const mgs_tracking_so_args* args, vo
     B.sketch_ws = args->sketch_ws;
     // only grad_sketch_dtau is consumed by the LM step: J-only backward (no per-splat sums,
     // no preprocess backward, no grad_tau)
-    if ((rc = raster_backward_impl(&B, stream, true, nullptr, nullptr, true, kept)) != MGS_OK) return fail(rc);
+    if ((rc = raster_backward_impl(&B, stream, true, nullptr, nullptr, true, kept, &fuse)) != MGS_OK) return fail(rc);
   }
   mgs_lm_step_args L = args->lm;
   L.SJ = nullptr; L.sj_tau = sj_tau; L.sj_exposure = sj_exp; L.Sf = Sf; L.rows = (int32_t)rows; L.loss = l1;

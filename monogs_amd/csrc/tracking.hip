@@ -14,6 +14,7 @@
 #include "../../include/monogs_raster.h"
 #include "launch.h"
 #include "objective_math.h"
+#include "sketch_kernels.h"
 
 namespace mgs {
 
@@ -799,30 +800,6 @@ __global__ __launch_bounds__(kLossBlock) void k_map_loss_fused(mgs_mapping_loss_
 }
 
 
-// ---------------------------------------------------------------------------------
-// Keyed pseudo-random permutation of [0, m): invertible rounds (add, odd multiply, xor-shift)
-// on `bits` = ceil(log2 m) bits, cycle-walked into range.  Every round is a bijection of
-// [0, 2^bits), so the composition is one, and walking a point of [0, m) along its cycle until
-// it lands in [0, m) again yields a bijection of [0, m).
-__device__ __forceinline__ unsigned int perm_round(unsigned int x, unsigned int mask, int bits,
-                                                   unsigned int k0, unsigned int k1) {
-  const int h = bits > 2 ? bits / 2 : 1;
-  x = (x + k0) & mask;
-  x = (x * 0x9E3779B1u) & mask;
-  x ^= x >> h;
-  x = (x * 0x85EBCA6Bu) & mask;
-  x = (x + k1) & mask;
-  x ^= x >> (h > 1 ? h - 1 : 1);
-  x = (x * 0xC2B2AE35u) & mask;
-  x ^= x >> h;
-  return x;
-}
-
-__device__ __forceinline__ unsigned int hash32(unsigned int x) {
-  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-  return x;
-}
-
 __global__ __launch_bounds__(256) void k_sketch_assign(long long m, int chunk, int d, int bits,
                                                        unsigned int k0, unsigned int k1, unsigned int k2,
                                                        int* bucket, float* weights) {
@@ -836,67 +813,10 @@ __global__ __launch_bounds__(256) void k_sketch_assign(long long m, int chunk, i
   }
 }
 
-constexpr int kSketchBlocks = 256;   // one workgroup per CU (12 KB of LDS bucket sums each)
-
-struct SketchKeys { int on, chunk, bits; unsigned int k0, k1, k2; };   // on != 0: assign bucket / weight here
-
-__global__ __launch_bounds__(kLossBlock) void k_sketch_residual(mgs_sketch_residual_args A, SketchKeys K) {
+__global__ __launch_bounds__(kSketchThreads) void k_sketch_residual(mgs_sketch_residual_args A, SketchKeys K) {
   extern __shared__ float s_acc[];   // [d][3]: Sf, d/da, d/db
-  __shared__ float s_red[kLossBlock / 64];
-  const int d = A.stack_dim * A.sketch_dim;
-  for (int i = threadIdx.x; i < 3 * d; i += kLossBlock) s_acc[i] = 0.f;
-  __syncthreads();
-  const float a = A.exposure_a[0];
-  const float gain = fabsf(a) + A.exposure_eps, bias = A.exposure_b[0];
-  const float sg = a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f);
-  const size_t HW = (size_t)A.num_pixels;
-  const float scale = (float)d / (float)A.num_pixels;      // 1 / (m / (stack * sketch))
-  float l1 = 0.f;
-  for (size_t p = (size_t)blockIdx.x * kLossBlock + threadIdx.x; p < HW; p += (size_t)gridDim.x * kLossBlock) {
-    const float om = A.opacity[p] * (A.mask ? A.mask[p] : 1.f);
-    int b;
-    float wsign;
-    if (K.on) {    // the partition of mgs_sketch_assign, evaluated (and left behind for the backward) in this pass
-      const unsigned int pmask = K.bits >= 32 ? 0xFFFFFFFFu : ((1u << K.bits) - 1u);
-      unsigned int x = (unsigned int)p;
-      do { x = perm_round(x, pmask, K.bits, K.k0, K.k1); } while ((size_t)x >= HW);
-      b = (long long)x < (long long)K.chunk * d ? (int)(x / (unsigned int)K.chunk) : -1;
-      wsign = (hash32((unsigned int)p ^ K.k2) & 0x10000u) ? 1.f : -1.f;
-      const_cast<int32_t*>(A.bucket)[p] = b;
-      const_cast<float*>(A.weights)[p] = wsign;
-    } else {
-      b = A.bucket[p];
-      wsign = A.weights[p];
-    }
-    const float w = wsign * scale;
-    float hs = 0.f, da = 0.f, db = 0.f;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      const float im = A.image[c * HW + p];
-      const float r = om * (gain * im + bias - A.gt[c * HW + p]);
-      l1 += fabsf(r);
-      float dh;
-      hs += huber(r, A.huber_delta, dh);
-      const float g = w * dh * om;              // d weighted / d (gain * image + bias)
-      A.grad_image[c * HW + p] = g * gain;
-      da += g * im;
-      db += g;
-    }
-    if (b >= 0 && b < d) {
-      atomicAdd(&s_acc[3 * b], w * hs);
-      atomicAdd(&s_acc[3 * b + 1], da * sg);
-      atomicAdd(&s_acc[3 * b + 2], db);
-    }
-  }
-  const float t = block_sum(l1, s_red);
-  if (threadIdx.x == 0) atomicAdd(A.l1, t);
-  __syncthreads();
-  for (int i = threadIdx.x; i < d; i += kLossBlock) {
-    const float f = s_acc[3 * i], x = s_acc[3 * i + 1], y = s_acc[3 * i + 2];
-    if (f != 0.f) atomicAdd(&A.Sf[i], f);
-    if (x != 0.f) atomicAdd(&A.sj_exposure[2 * i], x);
-    if (y != 0.f) atomicAdd(&A.sj_exposure[2 * i + 1], y);
-  }
+  __shared__ float s_red[kSketchThreads / 64];
+  sketch_residual_block(A, K, s_acc, s_red, blockIdx.x, gridDim.x);
 }
 
 static int loss_blocks(int64_t hw) {
@@ -983,23 +903,6 @@ int32_t mgs_lm_solve_step(const mgs_lm_step_args* a, void* stream) {
   return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
-// chunk size, index bits and the three 32-bit round keys (splitmix64 of the 64-bit key) of the partition
-static bool sketch_keys(int64_t num_pixels, int32_t stack_dim, int32_t sketch_dim, uint64_t key, SketchKeys& K) {
-  if (num_pixels < 1 || num_pixels > 0x7fffffffLL || stack_dim < 1 || sketch_dim < 1) return false;
-  const int d = stack_dim * sketch_dim;
-  K.chunk = (int)(num_pixels / d);
-  if (K.chunk < 1) return false;
-  K.bits = 1;
-  while ((1LL << K.bits) < num_pixels) K.bits++;
-  uint64_t z = key + 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
-  K.k0 = (unsigned int)z; K.k1 = (unsigned int)(z >> 32);
-  z = (z + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull; z ^= z >> 29;
-  K.k2 = (unsigned int)(z >> 16);
-  K.on = 1;
-  return true;
-}
-
 int32_t mgs_sketch_assign(int64_t num_pixels, int32_t stack_dim, int32_t sketch_dim, uint64_t key,
                           int32_t* bucket, float* weights, void* stream) {
   SketchKeys K;
@@ -1017,11 +920,11 @@ int32_t mgs_sketch_residual(const mgs_sketch_residual_args* a, void* stream) {
     return MGS_ERR_BAD_ARGUMENT;
   const size_t smem = sizeof(float) * 3 * (size_t)a->stack_dim * a->sketch_dim;
   if (smem > 48 * 1024) return MGS_ERR_UNSUPPORTED;
-  const int64_t want = (a->num_pixels + kLossBlock - 1) / kLossBlock;
+  const int64_t want = (a->num_pixels + kSketchThreads - 1) / kSketchThreads;
   const int nb = (int)(want < kSketchBlocks ? want : kSketchBlocks);
   SketchKeys K = {0, 0, 0, 0u, 0u, 0u};
   if (a->assign && !sketch_keys(a->num_pixels, a->stack_dim, a->sketch_dim, a->assign_key, K)) return MGS_ERR_BAD_ARGUMENT;
-  launch_smem("sketch_residual", k_sketch_residual, dim3(nb), dim3(kLossBlock), smem, (hipStream_t)stream, *a, K);
+  launch_smem("sketch_residual", k_sketch_residual, dim3(nb), dim3(kSketchThreads), smem, (hipStream_t)stream, *a, K);
   return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 
