@@ -175,6 +175,50 @@ def test_scale_modifier_and_isotropic_broadcast(built):
     _compare(gpu, ora)
 
 
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_configurations_match_the_oracle(built, seed):
+    """A seeded sweep over the argument space of the rasteriser's call (gaussian_renderer/__init__.py:61-75,151-168):
+    map size 1 ... 3000, image sizes that are not multiples of the tile, a moved camera, SH degree 0 ... 3 with an
+    active degree at or below the stored one, scale / rotation or a precomputed covariance, SH or precomputed colours,
+    isotropic scales, a scale modifier, a random background, depth gradients on or off: forward outputs and every
+    gradient sink against the autograd oracle on the same inputs."""
+    from monogs_amd import synthetic as S
+    from oracle import torch_raster as O
+    g = torch.Generator().manual_seed(1000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    rf = lambda lo, hi: float(lo + (hi - lo) * torch.rand(1, generator=g))
+    W, H = ri(33, 200), ri(17, 150)
+    N = [1, 2, 37, 300, 1000, 3000][seed % 6] if seed < 6 else ri(1, 3000)
+    sc = S.make_scene(N, W, H, seed=50 + seed)
+    tau = torch.tensor([rf(-0.08, 0.08), rf(-0.08, 0.08), rf(-0.1, 0.1), rf(-0.05, 0.05), rf(-0.05, 0.05), rf(-0.05, 0.05)])
+    cam = S.make_camera(W, H, O.se3_exp(tau))
+    sc = sc._replace(cam=cam)
+    stored = ri(0, 3)
+    active = ri(0, stored)
+    m, s_, r_, o, sh = _inputs(sc, deg=stored, seed=seed)
+    bg = torch.rand(3, generator=g)
+    mod = [1.0, 0.7, 1.3][ri(0, 2)]
+    campos = torch.linalg.inv(cam.viewmatrix.T)[:3, 3].contiguous() if ri(0, 1) else None     # true centre or MonoGS's quirk
+    use_cov, use_col, iso = ri(0, 3) == 0, ri(0, 3) == 0, ri(0, 3) == 0
+    col = cov6 = None
+    if iso:
+        s_ = s_[:, :1].repeat(1, 3).contiguous()
+    if use_cov:
+        Sig = O.cov3d_from_scale_rot(s_, r_, mod)
+        cov6 = torch.stack([Sig[:, 0, 0], Sig[:, 0, 1], Sig[:, 0, 2], Sig[:, 1, 1], Sig[:, 1, 2], Sig[:, 2, 2]], 1).contiguous()
+        s_ = r_ = None
+    if use_col:
+        col, sh = torch.rand(N, 3, generator=g), None
+    deg = 0 if use_col else active
+    gi, gd = torch.randn(3, H, W, generator=g), torch.randn(1, H, W, generator=g) * (0.0 if seed % 4 == 3 else 0.3)
+    loss_fn = lambda i, d: (i * gi.to(i.device)).sum() / (H * W) + (d * gd.to(d.device)).sum() / (H * W)
+    gpu = _run_gpu(sc, gpu_settings(cam, bg, _dev(), deg=deg, campos=campos, scale_modifier=mod), m, s_, r_, o, sh, col, cov6,
+                   loss_fn=loss_fn)
+    ora = _run_oracle(sc, oracle_settings(cam, bg, deg=deg, campos=campos, scale_modifier=mod), m, s_, r_, o, sh, col, cov6,
+                      loss_fn=loss_fn)
+    _compare(gpu, ora)
+
+
 def test_everything_culled_and_single_gaussian(built):
     from monogs_amd import synthetic as S
     dev = _dev()
