@@ -124,10 +124,8 @@ __device__ __forceinline__ int xcd_remap(int bid) {
 }
 inline int grid_pad(int n, int chunk) { const int q = 8 * chunk; return (n + q - 1) / q * q; }
 constexpr int kBwdChunk = 16;        // (8 / 32 / 64 re-measured with the 32-splat items: within 1 %)
-#ifndef MGS_SKETCH_REPS
-#define MGS_SKETCH_REPS 2
-#endif
-constexpr int kSketchReps = MGS_SKETCH_REPS;     // consecutive items per workgroup of the sketch-mode blend backward (1: 213 us, 2: 189, 4: 218)
+constexpr int kSketchReps = 2;     // consecutive items per workgroup of the sketch-mode blend backward (r3: 1 / 2 / 4: 213 / 189 / 218 us;
+                                   // r4, with slabs: 2 / 3 / 4: 178 / 192 / 214 us)
 
 constexpr uint64_t kAlign = 256;
 inline uint64_t align_up(uint64_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
