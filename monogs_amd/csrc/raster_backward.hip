@@ -771,6 +771,12 @@ __global__ __launch_bounds__(kPreBlock) void k_preprocess_bwd(KP P, KB B) {
       const KM& M = B.map;
       const bool add = M.accumulate != 0;
       auto put = [&](float* dst, float v) { *dst = add ? *dst + v : v; };
+      // Accumulating a view in which this Gaussian is not visible changes nothing: all its gradients and both
+      // statistics are zero - no read-modify-write of its 14 + 2 floats.  (Gaussians of old keyframes sit in
+      // contiguous index ranges: in a real window whole waves take this path.)  The regulariser, when this launch
+      // adds it, goes to every Gaussian.
+      const bool touch = !(add && !M.add_reg && radius <= 0);
+      if (touch) {
       // colour coefficients first: for degree > 0 sh_backward adds the view-direction term to dmean
       if constexpr (SH0) {
         float d3[3] = {0.f, 0.f, 0.f};
@@ -843,11 +849,14 @@ __global__ __launch_bounds__(kPreBlock) void k_preprocess_bwd(KP P, KB B) {
         if (add) { const float4 old = *dst; gq.x += old.x; gq.y += old.y; gq.z += old.z; gq.w += old.w; }
         *dst = gq;
       }
+      }   // touch
       // statistics of this view
       const bool vis = radius > 0;
-      if (M.gradnorm_inc) put(&M.gradnorm_inc[idx], vis ? sqrtf(dndc[0] * dndc[0] + dndc[1] * dndc[1]) : 0.f);
-      if (M.denom_inc) put(&M.denom_inc[idx], vis ? 1.f : 0.f);
-      if (M.radii_max) M.radii_max[idx] = add ? max(M.radii_max[idx], radius) : radius;
+      if (vis || !add) {
+        if (M.gradnorm_inc) put(&M.gradnorm_inc[idx], vis ? sqrtf(dndc[0] * dndc[0] + dndc[1] * dndc[1]) : 0.f);
+        if (M.denom_inc) put(&M.denom_inc[idx], vis ? 1.f : 0.f);
+        if (M.radii_max) M.radii_max[idx] = add ? max(M.radii_max[idx], radius) : radius;
+      }
       if (M.visibility) M.visibility[idx] = P.n_touched[idx] > 0 ? 1 : 0;
     } else if (B.g_means3D) {   // NULL: pose-only backward (tracking), nothing per Gaussian is stored
     // colours
