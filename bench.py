@@ -77,17 +77,24 @@ def parse(argv=None):
 
 
 def csrc_tree_hash():
-    """sha256 over the kernel sources (monogs_amd/csrc/*, include/monogs_raster.h; names and contents, sorted):
+    """sha256 over the kernel sources (monogs_amd/csrc/*, include/monogs_raster.h; names and contents without
+    comments and white space, sorted):
     what profiles/pmc_traffic.json was collected on must be what this run executes, or `roofline.traffic`
     is null (profiles/collect.sh stores the hash at collection)."""
     import hashlib
+    import re
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "monogs_amd", "csrc")
     files = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".h"))]
     files.append(os.path.join(ROOT, "include", "monogs_raster.h"))
     for f in files:
+        src = open(f, encoding="utf-8", errors="replace").read()
+        # comments and white space do not change the kernels: a reworded comment must not void the traffic figure
+        src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+        src = re.sub(r"//[^\n]*", " ", src)
+        src = " ".join(src.split())
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        h.update(src.encode())
     return h.hexdigest()[:16]
 
 

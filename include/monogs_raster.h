@@ -556,9 +556,9 @@ typedef struct mgs_tracking_so_args {
   float* accum;
   void* sketch_ws;           /* sketch_bytes of backward scratch */
   mgs_lm_step_args lm;       /* SJ / Sf / sj_* / loss fields are filled in by the call */
-  /* != 0: `accum` and `sketch_ws` were zero-filled before the FIRST call and nobody else writes them; the
-   * iteration's own kernels restore the zeros they need (the LM kernel: accum; the bucket kernel: the
-   * per-pixel Jacobian rows), so no hipMemsetAsync is enqueued per iteration */
+  /* != 0: `accum` was zero-filled before the FIRST call and nobody else writes it; the LM kernel - its consumer -
+   * restores the zeros, so no hipMemsetAsync is enqueued per iteration.  (`sketch_ws` needs no initial state:
+   * every launch rewrites what it reads - the per-run slabs of Jacobian rows and their masks.) */
   int32_t scratch_kept_zero;
   int32_t repeat_dim;        /* >= 1; 0 means 1 */
 } mgs_tracking_so_args;
