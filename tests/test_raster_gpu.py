@@ -370,18 +370,22 @@ def test_knn_dist2(built):
 # ---------------------------------------------------------------------------------------
 # sketched pose Jacobian (row a9) and the loop bodies (rows a12 / a13)
 # ---------------------------------------------------------------------------------------
-def test_sketched_pose_jacobian_matches_oracle(built):
+@pytest.mark.parametrize("N,W,H,repeat,stack,sketch,moved", [(600, 64, 48, 2, 2, 4, False), (500, 70, 45, 1, 3, 5, True)])
+def test_sketched_pose_jacobian_matches_oracle(built, N, W, H, repeat, stack, sketch, moved):
     """Same construction as the reference's only hot-path self check
     (utils/slam_frontend.py:1031-1127): the sketched Jacobian row of every bucket must equal
     the plain autograd gradient of that bucket's summed residual w.r.t. (trans, rot).  Here
-    the right-hand side comes from the CPU oracle instead of the extension itself."""
+    the right-hand side comes from the CPU oracle instead of the extension itself.
+    Second case: an image that is not a whole number of tiles (the per-tile slabs of Jacobian rows at the image
+    border), a pixel count that the buckets do not divide (left-over pixels belong to no bucket) and a moved camera."""
     from monogs_amd import synthetic as S
     from monogs_amd.rasterizer import GaussianRasterizer
     from monogs_amd.slam_loops import gen_forward_sketch_args
     from oracle import torch_raster as O
     dev = _dev()
-    N, W, H, repeat, stack, sketch = 600, 64, 48, 2, 2, 4
     sc = S.make_scene(N, W, H, seed=12)
+    if moved:
+        sc = sc._replace(cam=S.make_camera(W, H, O.se3_exp(torch.tensor([0.04, -0.03, 0.08, 0.02, -0.03, 0.02]))))
     m, s, r, o, sh = _inputs(sc)
     s = s * 1.5
     g = torch.Generator().manual_seed(3)
