@@ -1302,15 +1302,17 @@ def test_sketch_assign_is_a_random_partition_into_equal_buckets(built):
             prev = b
 
 
-def test_native_second_order_iteration_matches_python_formulation(built):
+@pytest.mark.parametrize("W,H", [(160, 120), (150, 101)])
+def test_native_second_order_iteration_matches_python_formulation(built, W, H):
     """mgs_tracking_iteration_second_order against tracking_step_second_order (the reference-
     shaped autograd formulation) on the SAME bucket partition and weights: Sf, the sketched
-    Jacobian SJ [d, 8], the LM step and the updated pose / exposure."""
+    Jacobian SJ [d, 8], the LM step and the updated pose / exposure.  (150x101: not a whole number of tiles, and
+    46 pixels left over by the 64 buckets.)"""
     from monogs_amd.gaussian_renderer import render
     from monogs_amd.pose import SE3_exp
     from monogs_amd.slam_loops import Pipe, sketch_args_from_buckets, tracking_step_second_order
     from monogs_amd.tracking_native import NativeTracker
-    sc, gauss, view, dev = _loop_fixture()
+    sc, gauss, view, dev = _loop_fixture(W=W, H=H)
     bg = torch.zeros(3, device=dev)
     with torch.no_grad():
         target = render(view(1, torch.eye(4)), gauss, Pipe, bg)["render"].clone()
