@@ -507,6 +507,9 @@ int32_t mgs_sketch_assign(int64_t num_pixels, int32_t stack_dim, int32_t sketch_
  *   r_c = opacity * mask * ((|a|+eps) image_c + b - gt_c);  l1 = sum |r_c|
  *   weighted_p = weights_p / (HW / (stack*sketch)) * sum_c Huber(r_c)
  *   Sf[b] += weighted_p;  sj_exposure[b] += d weighted_p / d(a, b);  grad_image = d weighted_p / d image
+ * with the derivatives through the exposure taken as the reference's hand-written ApplyExposure.backward takes
+ * them (slam_utils.py:145-149; NOT the exact derivative): d/d image carries |a| without eps, d/da carries
+ * image WITHOUT sign(a) - identical while exposure_a > 0, pinned for a < 0 by tests/golden/map_update_ref.npz.
  * Sf / sj_exposure / l1 must be zero on entry (they are accumulated with atomics). */
 typedef struct mgs_sketch_residual_args {
   const float* image;        /* [3,H,W] */
@@ -734,8 +737,11 @@ int32_t mgs_mapping_view_iteration(const mgs_mapping_view_args* args, void* stre
  * GaussianModel.reset_opacity / reset_opacity_nonvisible (gaussian_model.py:364-377 +
  * replace_tensor_to_optimizer :470-483): opacity logit <- inverse_sigmoid(reset_value) for every
  * Gaussian (reset_mode 1) or for those NOT visible in any view of this iteration, i.e.
- * denom_inc == 0 (reset_mode 2), and the opacity group's Adam moments zeroed (all of them,
- * as the reference does). */
+ * denom_inc == 0 (reset_mode 2, 3), and the opacity group's Adam moments zeroed (all of them,
+ * as the reference does).  reset_mode 2 is the reference to the letter: gaussian_model.py:375 stores
+ * the ACTIVATED opacity of a visible Gaussian as its new raw parameter, so its logit l becomes
+ * sigmoid(l) (pinned by tests/golden/map_update_ref.npz, generated from the reference's own code);
+ * reset_mode 3 leaves the visible Gaussians' logits untouched (what the code presumably meant). */
 typedef struct mgs_map_finish_args {
   int32_t num_gaussians;
   const float* gradnorm_inc;     /* [N] or NULL (no statistics this iteration) */
@@ -744,7 +750,7 @@ typedef struct mgs_map_finish_args {
   float* xyz_gradient_accum;     /* [N] */
   float* denom;                  /* [N] */
   float* max_radii2D;            /* [N] */
-  int32_t reset_mode;            /* 0 none, 1 reset_opacity, 2 reset_opacity_nonvisible */
+  int32_t reset_mode;            /* 0 none, 1 reset_opacity, 2 reset_opacity_nonvisible (reference), 3 same, visible logits kept */
   float reset_value;             /* 0.01 / 0.4 */
   float* opacity_logits;         /* [N] (reset_mode != 0) */
   float* opacity_exp_avg;        /* [N] or NULL */

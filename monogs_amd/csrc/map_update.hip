@@ -309,7 +309,13 @@ __global__ __launch_bounds__(256) void k_map_finish(mgs_map_finish_args A, float
     A.max_radii2D[i] = fmaxf(A.max_radii2D[i], (float)A.radii_max[i]);
   }
   if (A.reset_mode != 0) {
-    if (A.reset_mode == 1 || !(A.denom_inc[i] > 0.f)) A.opacity_logits[i] = reset_logit;
+    if (A.reset_mode == 1 || !(A.denom_inc[i] > 0.f)) {
+      A.opacity_logits[i] = reset_logit;
+    } else if (A.reset_mode == 2) {
+      // gaussian_model.py:375 stores `self.get_opacity[filter]` - the ACTIVATED opacity - as the new raw parameter of
+      // a visible Gaussian: its logit l becomes sigmoid(l) (pinned by tests/golden/map_update_ref.npz: ron_*)
+      A.opacity_logits[i] = 1.f / (1.f + expf(-A.opacity_logits[i]));
+    }
     if (A.opacity_exp_avg) A.opacity_exp_avg[i] = 0.f;
     if (A.opacity_exp_avg_sq) A.opacity_exp_avg_sq[i] = 0.f;
   }
@@ -447,11 +453,11 @@ int32_t mgs_map_activate(const mgs_map_activate_args* a, void* stream) {
 }
 
 int32_t mgs_map_finish_iteration(const mgs_map_finish_args* a, void* stream) {
-  if (!a || a->num_gaussians < 1 || a->reset_mode < 0 || a->reset_mode > 2) return MGS_ERR_BAD_ARGUMENT;
+  if (!a || a->num_gaussians < 1 || a->reset_mode < 0 || a->reset_mode > 3) return MGS_ERR_BAD_ARGUMENT;
   if (a->gradnorm_inc && (!a->denom_inc || !a->radii_max || !a->xyz_gradient_accum || !a->denom || !a->max_radii2D))
     return MGS_ERR_BAD_ARGUMENT;
   if (a->reset_mode != 0 && (!a->opacity_logits || !(a->reset_value > 0.f) || !(a->reset_value < 1.f))) return MGS_ERR_BAD_ARGUMENT;
-  if (a->reset_mode == 2 && !a->denom_inc) return MGS_ERR_BAD_ARGUMENT;
+  if (a->reset_mode >= 2 && !a->denom_inc) return MGS_ERR_BAD_ARGUMENT;
   if (!a->gradnorm_inc && a->reset_mode == 0) return MGS_OK;
   // inverse_sigmoid(x) = log(x / (1 - x))   (gaussian_splatting/utils/general_utils.py)
   const float logit = a->reset_mode ? (float)log((double)a->reset_value / (1.0 - (double)a->reset_value)) : 0.f;

@@ -47,9 +47,13 @@ __device__ __forceinline__ void sketch_residual_block(const mgs_sketch_residual_
   const int d = A.stack_dim * A.sketch_dim;
   for (int i = threadIdx.x; i < 3 * d; i += kSketchThreads) s_acc[i] = 0.f;
   __syncthreads();
-  const float a = A.exposure_a[0];
-  const float gain = fabsf(a) + A.exposure_eps, bias = A.exposure_b[0];
-  const float sg = a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f);
+  // The sketched path goes through the reference's hand-written ApplyExposure.backward (utils/slam_utils.py:145-149),
+  // which is NOT the exact derivative of (|a| + eps) image + b: grad_image = |a| grad (no eps) and
+  // grad_a = sum(grad image) (no sign(a)).  Followed to the letter here (pinned by tests/golden/map_update_ref.npz:
+  // ae_*); the first-order path differentiates the same expression by autograd and keeps sign(a) and eps
+  // (k_track_loss_bwd / _onepass, the forward blend's objective epilogue).
+  const float gain_bwd = fabsf(A.exposure_a[0]);
+  const float gain = gain_bwd + A.exposure_eps, bias = A.exposure_b[0];
   const size_t HW = (size_t)A.num_pixels;
   const float scale = (float)d / (float)A.num_pixels;      // 1 / (m / (stack * sketch))
   float l1 = 0.f;
@@ -79,13 +83,13 @@ __device__ __forceinline__ void sketch_residual_block(const mgs_sketch_residual_
       float dh;
       hs += huber(r, A.huber_delta, dh);
       const float g = w * dh * om;              // d weighted / d (gain * image + bias)
-      A.grad_image[c * HW + p] = g * gain;
+      A.grad_image[c * HW + p] = g * gain_bwd;
       da += g * im;
       db += g;
     }
     if (b >= 0 && b < d) {
       atomicAdd(&s_acc[3 * b], w * hs);
-      atomicAdd(&s_acc[3 * b + 1], da * sg);
+      atomicAdd(&s_acc[3 * b + 1], da);
       atomicAdd(&s_acc[3 * b + 2], db);
     }
   }

@@ -246,12 +246,14 @@ class GaussianModel:
         """opacity <- 0.01 for every Gaussian, the opacity group's Adam moments zeroed (:364-367)."""
         self._reset(1, 0.01, None)
 
-    def reset_opacity_nonvisible(self, visibility_filters):
-        """opacity <- 0.4 for the Gaussians outside every filter (:369-377)."""
+    def reset_opacity_nonvisible(self, visibility_filters, keep_visible_logits=False):
+        """opacity <- 0.4 for the Gaussians outside every filter (:369-377).  As in the reference, a Gaussian
+        INSIDE a filter gets its activated opacity as the new raw parameter (:375: logit <- sigmoid(logit));
+        `keep_visible_logits=True` leaves those logits alone instead."""
         seen = torch.zeros(len(self), device=self.device)
         for f in visibility_filters:
             seen += f.to(self.device, torch.float32)
-        self._reset(2, 0.4, seen)
+        self._reset(3 if keep_visible_logits else 2, 0.4, seen)
 
     def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, noise=None, generator=None):
         _densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, noise=noise, generator=generator)

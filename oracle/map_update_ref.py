@@ -3,8 +3,15 @@ to check monogs_amd/map_update.py:
   * densify_and_prune / densify_and_clone / densify_and_split / prune_points /
     densification_postfix / cat_tensors_to_optimizer / _prune_optimizer of
     /root/reference/gaussian_splatting/scene/gaussian_model.py:485-691
+  * reset_opacity / reset_opacity_nonvisible / replace_tensor_to_optimizer (:364-377, :470-483),
+    add_densification_stats (:693-697)
 written against a plain dict-of-tensors state instead of nn.Parameters + torch.optim state,
 so results can be compared tensor by tensor.  The split's random draw (:609) is an argument.
+
+PINNED since round 5: tests/golden/map_update_ref.npz holds what the reference's own GaussianModel returned
+on seeded inputs (tests/golden/make_map_update_golden.py runs it on the CPU in the build container);
+tests/test_cpu_map_update_golden.py holds every function below to those arrays, and the GPU tests check the
+HIP path against the SAME arrays.
 """
 from __future__ import annotations
 
@@ -91,3 +98,43 @@ def densify_and_prune(state, max_grad, min_opacity, extent, max_screen_size, per
 
 def prune_points(state, mask):
     return _select(state, ~mask)
+
+
+def inverse_sigmoid(x):
+    """general_utils.py:18-19."""
+    return torch.log(x / (1 - x))
+
+
+def reset_opacity(state):
+    """:364-367 + replace_tensor_to_optimizer (:470-483): every logit <- inverse_sigmoid(0.01), the opacity
+    group's Adam moments zeroed; nothing else is touched."""
+    out = dict(state)
+    out["opacity"] = inverse_sigmoid(torch.ones_like(state["opacity"]) * 0.01)
+    out["exp_avg_opacity"] = torch.zeros_like(state["opacity"])
+    out["exp_avg_sq_opacity"] = torch.zeros_like(state["opacity"])
+    return out
+
+
+def reset_opacity_nonvisible(state, visibility_filters):
+    """:369-377.  Gaussians outside every filter get the logit of 0.4.  A reference quirk that this
+    restatement keeps (the fixture pins it): for a Gaussian INSIDE a filter the reference stores
+    `self.get_opacity[filter]` - the ACTIVATED opacity sigmoid(logit) - as the new raw parameter (:375), so a
+    visible Gaussian's logit l becomes sigmoid(l).  The opacity group's Adam moments are zeroed for all."""
+    out = dict(state)
+    new = inverse_sigmoid(torch.ones_like(state["opacity"]) * 0.4)
+    act = torch.sigmoid(state["opacity"])
+    for f in visibility_filters:
+        new[f] = act[f]
+    out["opacity"] = new
+    out["exp_avg_opacity"] = torch.zeros_like(new)
+    out["exp_avg_sq_opacity"] = torch.zeros_like(new)
+    return out
+
+
+def add_densification_stats(grad_accum, denom, viewspace_grad, update_filter):
+    """:693-697: the norm of the first two columns of the screen-space gradient is added, and the counter
+    incremented, where the filter holds."""
+    ga, dn = grad_accum.clone(), denom.clone()
+    ga[update_filter] += torch.norm(viewspace_grad[update_filter, :2], dim=-1, keepdim=True)
+    dn[update_filter] += 1
+    return ga, dn

@@ -315,9 +315,12 @@ def test_reset_opacity_and_nonvisible(built):
     keep = gm._opacity.detach().clone()
     vis1 = torch.zeros(500, dtype=torch.bool, device=dev); vis1[:100] = True
     vis2 = torch.zeros(500, dtype=torch.bool, device=dev); vis2[50:200] = True
-    gm.reset_opacity_nonvisible([vis1, vis2])
+    gm.reset_opacity_nonvisible([vis1, vis2], keep_visible_logits=True)
     want = math.log(0.4 / 0.6)
     assert torch.equal(gm._opacity[:200], keep[:200])
+    gm._opacity.data.copy_(keep)
+    gm.reset_opacity_nonvisible([vis1, vis2])         # the reference to the letter (gaussian_model.py:375)
+    assert torch.allclose(gm._opacity[:200], torch.sigmoid(keep[:200]), rtol=1e-6, atol=1e-7)
     assert torch.allclose(gm._opacity[200:], torch.full_like(gm._opacity[200:], want), atol=1e-6)
     st = gm.optimizer.state[gm._opacity]
     assert float(st["exp_avg"].abs().max()) == 0.0 and float(st["exp_avg_sq"].abs().max()) == 0.0

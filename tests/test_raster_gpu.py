@@ -1303,12 +1303,15 @@ def test_sketch_assign_is_a_random_partition_into_equal_buckets(built):
             prev = b
 
 
-@pytest.mark.parametrize("W,H", [(160, 120), (150, 101)])
-def test_native_second_order_iteration_matches_python_formulation(built, W, H):
+@pytest.mark.parametrize("W,H,gain", [(160, 120, 0.97), (150, 101, 0.97), (160, 120, -0.97)])
+def test_native_second_order_iteration_matches_python_formulation(built, W, H, gain):
     """mgs_tracking_iteration_second_order against tracking_step_second_order (the reference-
     shaped autograd formulation) on the SAME bucket partition and weights: Sf, the sketched
     Jacobian SJ [d, 8], the LM step and the updated pose / exposure.  (150x101: not a whole number of tiles, and
-    46 pixels left over by the 64 buckets.)"""
+    46 pixels left over by the 64 buckets.)  gain < 0: exposure_a negative, where the reference's hand-written
+    ApplyExposure.backward (slam_utils.py:145-149: no sign(a)) and the exact derivative part ways - the Python
+    formulation differentiates through losses.ApplyExposure, which tests/test_cpu_map_update_golden.py pins to the
+    reference's own outputs, and the native iteration must take the same (reference) step."""
     from monogs_amd.gaussian_renderer import render
     from monogs_amd.pose import SE3_exp
     from monogs_amd.slam_loops import Pipe, sketch_args_from_buckets, tracking_step_second_order
@@ -1323,7 +1326,7 @@ def test_native_second_order_iteration_matches_python_formulation(built, W, H):
         v.original_image = target
         v.rgb_pixel_mask_mapping = (target.sum(0) > 0.01).view(1, *target.shape[1:])
         with torch.no_grad():
-            v.exposure_a.fill_(0.97)
+            v.exposure_a.fill_(gain)
             v.exposure_b.fill_(0.01)
     H, W = va.image_height, va.image_width
     stack, sketch, lam = 4, 16, 1e-3
@@ -1333,7 +1336,7 @@ def test_native_second_order_iteration_matches_python_formulation(built, W, H):
     vc = view(4, T0)
     vc.original_image, vc.rgb_pixel_mask_mapping = target, vb.rgb_pixel_mask_mapping
     with torch.no_grad():
-        vc.exposure_a.fill_(0.97)
+        vc.exposure_a.fill_(gain)
         vc.exposure_b.fill_(0.01)
     trk_fast = NativeTracker(vc, gauss, bg)
     trk_fast.enable_second_order(stack_dim=stack, sketch_dim=sketch, initial_lambda=lam, seed=5)
@@ -1351,6 +1354,9 @@ def test_native_second_order_iteration_matches_python_formulation(built, W, H):
     assert rel_err(trk.so_x, x) < 5e-3
     assert torch.allclose(va.T, vb.T, atol=1e-4)
     assert torch.allclose(va.exposure_a, vb.exposure_a, atol=1e-4)
+    if gain < 0:      # the step on `a` has the sign the reference's Jacobian gives it, not the exact derivative's
+        assert rel_err(SJ_n[:, 6], SJ[:, 6]) < 1e-4 and float((SJ_n[:, 6] * SJ[:, 6]).sum()) > 0
+        return
     st = state.cpu()
     assert abs(st[0].item() - lam) < 1e-9 and st[2].item() == 1.0
     # trust-region rule on the device: the loss decreased after a good step -> lambda / 5
@@ -1366,7 +1372,7 @@ def test_native_second_order_iteration_matches_python_formulation(built, W, H):
     vd = view(5, T0)
     vd.original_image, vd.rgb_pixel_mask_mapping = target, vb.rgb_pixel_mask_mapping
     with torch.no_grad():
-        vd.exposure_a.fill_(0.97)
+        vd.exposure_a.fill_(gain)
         vd.exposure_b.fill_(0.01)
     trk_ref = NativeTracker(vd, gauss, bg)
     trk_ref.enable_second_order(stack_dim=stack, sketch_dim=sketch, initial_lambda=lam, seed=5, keep_sketch=True)
