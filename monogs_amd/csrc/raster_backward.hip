@@ -173,6 +173,10 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
   // tile, index of the item's first key, number of splats (<= kItem), position in the tile's list.
   const int4 sr = P.seg_rec[item];
   const int tile = sr.x, k0 = sr.y, nb = sr.z, base = sr.w;
+  // ... and, beside it, which of the item's splats can reach each quadrant of the tile: the 32-bit halves of the
+  // ballots the forward's quadrant waves formed over their 64-splat segments (exact box test, raster_forward.hip).
+  // Until round 5 every staged lane repeated the four box tests here: ~12 of the kernel's 73 VALU instructions per pair.
+  const uint4 rw = P.reach[item];
   MGS_BFINE(0, "s_waitcnt lgkmcnt(0)");
   MGS_BITEM(item, base);
   if constexpr (SKETCH) {
@@ -423,9 +427,8 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
     // does any pixel of the tile reach this segment?  (if not, none of the later ones either,
     // but their pairs still need their zero records)
     const bool dead = tile_last <= sub_base;
-    // stage the segment's records (one per lane): slot, raw conic, quadrant reach mask
+    // stage the segment's records (one per lane): slot, raw conic
     slot = -1;
-    unsigned int mask4 = 0;
     if (sub > 0) wave_lds_fence();    // the staged records belong to this wave alone: no workgroup barrier
     if (lane < nsub) {
       const unsigned int id = P.pack ? lo >> kPackBits : lo;
@@ -447,15 +450,6 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
 #pragma unroll
           for (int i = 0; i < 9; i++) s_coef[lane][i] = cj[i];
         }
-        const float qmax = splat_qmax(qa.w);
-        const float Wm = (float)(P.W - 1), Hm = (float)(P.H - 1);
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const float x0 = (float)(tx * kTile + 8 * (q & 1)), y0 = (float)(ty * kTile + 8 * (q >> 1));
-          if (sub_base + lane < qlast[q] && x0 <= Wm && y0 <= Hm &&
-              box_reachable(qa.x, qa.y, qb.x, qb.y, qb.z, qmax, x0, y0, fminf(x0 + 7.f, Wm), fminf(y0 + 7.f, Hm)))
-            mask4 |= 1u << q;
-        }
       }
     }
     written = 0ull;
@@ -463,8 +457,15 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
       // quadrant reach masks of the whole segment as four wave-uniform 64-bit words (bit j = splat
       // j reaches quadrant q): they live in SGPRs, so the walk below skips unreachable splats and
       // quadrants with scalar bit tests - no LDS round trip in front of every splat
+      // (a splat behind the quadrant's last contribution cannot contribute - the forward had stopped visiting the
+      // saturated quadrant, and did not write reach words any more: only the first qlast - base bits are kept)
+      static_assert(kItem <= 32, "a reach word per (item, quadrant) covers 32 splats");
+      const unsigned int rwq[4] = {rw.x, rw.y, rw.z, rw.w};
 #pragma unroll
-      for (int q = 0; q < 4; q++) mq[q] = __builtin_amdgcn_ballot_w64((mask4 >> q) & 1u);
+      for (int q = 0; q < 4; q++) {
+        const int keep = min(max(qlast[q] - sub_base, 0), nsub);
+        mq[q] = (unsigned long long)(rwq[q] & (unsigned int)((1ull << keep) - 1ull));
+      }
       wave_lds_fence();
       // Walk over the splats that reach any quadrant (set bits of the union mask), two-way
       // unrolled with the NEXT splat's record prefetched from LDS above the arithmetic of the

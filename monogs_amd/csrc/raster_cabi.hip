@@ -93,6 +93,7 @@ int fill_kp(const mgs_forward_args& a, bool need_bins, bool need_outputs, KP& P)
   P.payload = b ? (unsigned int*)(b + L.payload) : nullptr;
   P.seg_rec = b ? (int4*)(b + L.seg_rec) : nullptr;
   P.ckpt = b ? (float*)(b + L.ckpt) : nullptr;
+  P.reach = b ? (uint4*)(b + L.reach) : nullptr;
   P.max_segs = (int)L.max_segs;
   P.out_color = a.out_color; P.out_depth = a.out_depth; P.out_opacity = a.out_opacity;
   P.radii = a.radii; P.n_touched = a.n_touched; P.d_out = a.pair_count_out; P.d_max = a.pair_count_max;

@@ -916,6 +916,12 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
     __builtin_amdgcn_sched_barrier(0);
     if (touched_prev > 0) atomicAdd(&P.n_touched[cid_prev], touched_prev);   // previous segment's counts
     if constexpr (kParts > 1) flush_mid();
+    {   // this quadrant's reach bits of the segment's backward items: lane l stores the word of item base / kItem + l
+      static_assert(kItem == 32 && kSeg == 64, "one 32-bit reach word per (item, quadrant)");
+      const int sgr = seg0 + base / kItem + lane;
+      if (lane < 2 && base + lane * kItem < n && sgr < P.max_segs)
+        reinterpret_cast<unsigned int*>(P.reach)[4 * (size_t)sgr + quad] = lane ? (unsigned int)(m >> 32) : (unsigned int)m;
+    }
     if (base > 0 && base % kItem == 0) {   // checkpoint: state in front of this backward item
       const int sg = seg0 + base / kItem;
       if (sg < P.max_segs) {

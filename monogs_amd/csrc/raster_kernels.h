@@ -57,6 +57,9 @@ struct KP {
   unsigned int* payload;
   int4* seg_rec;           // backward item -> (tile, first key index, splats in the item, position in the list)
   float* ckpt;             // per item: float4[256] (T, C0, C1, C2) then float[256] D: blend state before its first splat
+  uint4* reach;            // per item: for each quadrant of its tile, bit j = splat j of the item can reach the quadrant
+                           // (the forward's quadrant waves form these ballots anyway; the backward reads them with the
+                           // item record instead of repeating four box tests per staged splat: round 5)
   int max_segs;
   // forward outputs
   float *out_color, *out_depth, *out_opacity;
@@ -133,7 +136,7 @@ inline uint64_t align_up(uint64_t v) { return (v + kAlign - 1) / kAlign * kAlign
 struct Layout {
   uint64_t rec, pair_count, pair_off, hit_mask, block_prefix, scan_tmp, tile_count, tile_offset, tile_cursor, bin_table, final_TC, final_DL,
       quad_last, seg_offset, obj_partial, counters, geom_bytes;
-  uint64_t keys, payload, seg_rec, ckpt, max_segs, bins_bytes;
+  uint64_t keys, payload, seg_rec, reach, ckpt, max_segs, bins_bytes;
   uint64_t pair_grad, tau_partial, bwd_bytes;
   uint64_t slab_mask, slabs, splat_jac, sketch_bytes;
 };
@@ -201,6 +204,7 @@ inline Layout make_layout(const mgs_raster_shape& s) {
   L.payload = o; o = align_up(o + cap * 4);
   L.max_segs = cap / kItem + T;
   L.seg_rec = o; o = align_up(o + L.max_segs * 16);
+  L.reach = o; o = align_up(o + L.max_segs * 16);
   L.ckpt = o; o = align_up(o + L.max_segs * 5 * 256 * 4);
   L.bins_bytes = o;
   o = 0;
