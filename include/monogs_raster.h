@@ -57,9 +57,10 @@ typedef struct mgs_raster_shape {
 typedef struct mgs_workspace_sizes {
   uint64_t geom_bytes;   /* per-Gaussian records, per-tile ranges, per-pixel blend state;
                             written by forward, read by backward (save it on the autograd ctx) */
-  uint64_t bins_bytes;   /* pair_capacity sorted (key, payload) pairs + per-item records and blend checkpoints (5 KB per 32 pairs and per tile); forward -> backward */
+  uint64_t bins_bytes;   /* pair_capacity sorted (key, payload) pairs + per-item records, quadrant reach words and blend checkpoints (5 KB + 32 B per 32 pairs and per tile); forward -> backward */
   uint64_t bwd_bytes;    /* backward-only scratch (per-pair reduced gradients, scans) */
-  uint64_t sketch_bytes; /* extra backward scratch, only when sketch_mode != 0 */
+  uint64_t sketch_bytes; /* extra backward scratch, only when sketch_mode != 0: 144 B per Gaussian + one 6-KB slab per TWO
+                            backward items and per tile, i.e. ~96 B per pair of capacity + 6 KB per tile (no initial state needed) */
   /* byte offsets inside `geom` of arrays tests may inspect */
   uint64_t off_records;      /* N x 48 B  mgs SplatRec                       */
   uint64_t off_pair_count;   /* N x int32 pairs emitted per Gaussian         */
@@ -189,7 +190,9 @@ typedef struct mgs_backward_args {
    * exact D from the pinned slot before the backward is enqueued), 0 = none.  Sizes the grid of the blend
    * backward: D / 32 + tiles work items instead of pair_capacity / 32 + tiles.  A value BELOW the true count
    * loses work items - the native entry points, which cannot know D of the forward they have just enqueued,
-   * leave it 0. */
+   * leave it 0.  The kernel notices: counters[2] of the geom workspace (int32 at off_counters + 8, zeroed by every
+   * forward) is set to the item count by a backward whose grid did not cover the forward's items - its gradients
+   * are then incomplete (the Python binding passes the exact D and checks the word when raster_settings.debug). */
   int32_t pair_count_bound;
 } mgs_backward_args;
 

@@ -117,13 +117,16 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
   // the constant address space into SGPRs, v_pk_fma_f32 with scalar operands, no LDS staging: 124 -> 115 VGPRs, 106
   // SGPRs with 4 spilled, and 176.6 -> 185.8 us: the loads cannot be issued a splat ahead (72 SGPRs) and their
   // latency sits in the walk.  profiles/r04_backward_blend_tuning.txt.)
-  // Sketch mode: a workgroup takes kSketchReps consecutive items (mostly of one tile) and adds its
-  // per-pixel Jacobian rows to pix_jac once per tile instead of once per item: the atomics, not the
-  // walk, bound that variant, and the 32-splat items doubled them.
+  // Sketch mode: a workgroup takes kSketchReps consecutive items (mostly of one tile) and leaves its per-pixel
+  // Jacobian rows as ONE slab per run of items of a tile (plain coalesced stores, flush_jacobian below) instead of
+  // one per item; k_sketch_bucket adds up a tile's slabs.
   constexpr int kReps = SKETCH ? kSketchReps : 1;
   const int n_items = min(P.seg_offset[P.T], P.max_segs);
   int item_first = xcd_remap<kBwdChunk>(blockIdx.x) * kReps;
   const int lane = threadIdx.x;
+  // A grid sized from a pair_count_bound BELOW the forward's pair count leaves the trailing items unwalked (their pair
+  // records unwritten): say so in counters[2] (zeroed by every forward; include/monogs_raster.h: mgs_backward_args).
+  if (blockIdx.x == 0 && lane == 0 && (long long)gridDim.x * kReps < (long long)n_items) P.counters[2] = n_items;
   MGS_BORDER(item_first, SKETCH);
   if (item_first < 0) return;
   if (item_first >= n_items) return;
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
 #pragma unroll
     for (int t = 0; t < 3; t++) J2[q][t] = v2f{0.f, 0.f};
   unsigned int jq_mask = 0u;       // quadrants in which this lane's rows received a contribution
-  int jtile = -1, jitem = 0;       // the tile in hand and the first item of this wave's run in it (= its slab)
+  int jtile = -1, jitem = 0;       // the tile in hand and the slab of this wave's run in it (slab_index of the run's first item)
   auto flush_jacobian = [&]() {
     if constexpr (SKETCH) {
       if (jtile < 0) return;
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
   MGS_BFINE(0, "s_waitcnt lgkmcnt(0)");
   MGS_BITEM(item, base);
   if constexpr (SKETCH) {
-    if (tile != jtile) { flush_jacobian(); jtile = tile; jitem = item; }
+    if (tile != jtile) { flush_jacobian(); jtile = tile; jitem = slab_index(item, tile); }
   }
   if (nb <= 0) continue;
   __builtin_assume(nb <= kItem);
@@ -518,8 +521,10 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
 //   k_sketch_prep    per Gaussian: d(x, y, A, B, C, depth)/d tau (6 x 6) by six unit-gradient
 //                    calls of the same chain used for the ordinary backward, folded with the
 //                    conic into 36 polynomial coefficients
-//   k_blend_bwd<1>   per (pixel, splat): J_p += W * poly(dx, dy) + w dL/dD * c  (6 components)
-//   k_sketch_bucket  per pixel: J_p -> LDS-privatised bucket table -> grad_sketch_dtau
+//   k_blend_bwd<1>   per (pixel, splat): J_p += W * poly(dx, dy) + w dL/dD * c  (6 components) in registers; the rows of
+//                    every run of consecutive items of one tile a wave walked leave as one SLAB (float[6][256],
+//                    quadrant-major, plain stores) + a mask word of the quadrants written
+//   k_sketch_bucket  per tile: adds up its slabs; per pixel: row -> LDS-privatised bucket table -> grad_sketch_dtau
 __device__ __forceinline__ void sketch_prep_gaussian(const KP& P, const KB& B, int idx) {
   if (idx >= P.N) return;
   const float4 r1 = reinterpret_cast<const float4*>(P.rec + idx)[1];
@@ -601,8 +606,9 @@ __global__ __launch_bounds__(kBucketThreads) void k_sketch_bucket(KP P, KB B) {
     // (with a branch per slab the ~10 slabs of a tile were ten dependent round trips).
 #pragma unroll 4
     for (int i = a; i < b; i = (i / kSketchReps + 1) * kSketchReps) {       // wave-uniform
-      const bool on = (B.slab_mask[i] >> q) & 1u;
-      const float* slab = B.slabs + (size_t)i * (6 * 256) + tid;
+      const int sid = slab_index(i, tile);
+      const bool on = (B.slab_mask[sid] >> q) & 1u;
+      const float* slab = B.slabs + (size_t)sid * (6 * 256) + tid;
 #pragma unroll
       for (int t = 0; t < 6; t++) {
         const float v = slab[t * 256];

@@ -102,8 +102,8 @@ struct KB {   // backward extras
   // k_sketch_bucket adds up a tile's slabs (until round 4 the rows met in a per-pixel array through float atomics:
   // 75 MB of 32-B-segment atomics per launch bounded the kernel).  slab_mask[i] = quadrants written (every run
   // start is written by every launch, so nothing is ever stale).
-  float* slabs;            // max_segs x 6 x 256
-  unsigned int* slab_mask; // max_segs
+  float* slabs;            // (max_segs / kSketchReps + T + 1) x 6 x 256, indexed by slab_index()
+  unsigned int* slab_mask; // one word per slab
   float* splat_jac;        // N x 36 per-splat d(xy,conic,depth)/dtau (sketch mode)
   KM map;
 };
@@ -129,6 +129,11 @@ inline int grid_pad(int n, int chunk) { const int q = 8 * chunk; return (n + q -
 constexpr int kBwdChunk = 16;        // (8 / 32 / 64 re-measured with the 32-splat items: within 1 %)
 constexpr int kSketchReps = 2;     // consecutive items per workgroup of the sketch-mode blend backward (r3: 1 / 2 / 4: 213 / 189 / 218 us;
                                    // r4, with slabs: 2 / 3 / 4: 178 / 192 / 214 us)
+
+// Slab of the run of backward items that starts at item `item` of tile `tile` (sketch mode): runs start at a tile's
+// first item and at every multiple of kSketchReps, so item / kSketchReps + tile is strictly increasing along the run
+// starts - unique - and stays below max_segs / kSketchReps + T + 1: half the slabs one per item would take.
+__host__ __device__ inline int slab_index(int item, int tile) { return item / kSketchReps + tile; }
 
 constexpr uint64_t kAlign = 256;
 inline uint64_t align_up(uint64_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
@@ -213,9 +218,10 @@ inline Layout make_layout(const mgs_raster_shape& s) {
   L.tau_partial = o; o = align_up(o + npre * 6 * 4);
   L.bwd_bytes = o;
   o = 0;
-  L.slab_mask = o; o = align_up(o + (L.max_segs + 1) * 4);
+  const uint64_t nslabs = L.max_segs / kSketchReps + T + 1;      // slab_index() of the last possible run start + 1
+  L.slab_mask = o; o = align_up(o + nslabs * 4);
   L.splat_jac = o; o = align_up(o + N * 36 * 4);
-  L.slabs = o; o = align_up(o + L.max_segs * 6 * 256 * 4);
+  L.slabs = o; o = align_up(o + nslabs * 6 * 256 * 4);
   L.sketch_bytes = o;
   return L;
 }

@@ -53,6 +53,7 @@ def set_clamp_gradient_mode(mode: str) -> None:
 _capacity_hint: dict = {}
 _tile_max_hint: dict = {}
 _bwd_scratch: dict = {}
+_sketch_scratch: dict = {}
 last_stats: dict = {}
 
 
@@ -296,11 +297,22 @@ class _RasterizeGaussians(torch.autograd.Function):
             idx = idx_all[ctx.repeat_iter].contiguous()   # [stack,H,W] int32
             ctx.repeat_iter += 1
             g_sketch = torch.empty(stack_dim, sketch_dim, 6, dtype=torch.float32, device=dev)
-            sk_ws = torch.empty(int(pre["sizes"].sketch_bytes), dtype=torch.uint8, device=dev)
+            # per-(device, stream) scratch like the backward's own: it is dead once the launch sequence has run,
+            # needs no initial state, and at ~100 B per pair of capacity is too large to allocate per repeat
+            skey = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+            sk_ws = _sketch_scratch.get(skey)
+            if sk_ws is None or sk_ws.numel() < int(pre["sizes"].sketch_bytes):
+                sk_ws = _sketch_scratch[skey] = torch.empty(int(pre["sizes"].sketch_bytes), dtype=torch.uint8, device=dev)
             keep += [idx, sk_ws]
             b.sketch_mode, b.sketch_dim, b.stack_dim = sketch_mode, sketch_dim, stack_dim
             b.sketch_indices, b.grad_sketch_dtau, b.sketch_ws = _ptr(idx), _ptr(g_sketch), _ptr(sk_ws)
         _cabi.check(lib.mgs_raster_backward(C.byref(b), _stream_ptr(dev)), "mgs_raster_backward")
+        if st.debug:      # as upstream: device-side checks only in debug mode (they cost a host sync)
+            off = int(pre["sizes"].off_counters)
+            short = int(saved[12][off + 8:off + 12].view(torch.int32).item())
+            if short:
+                raise RuntimeError(f"mgs_raster_backward: pair_count_bound {int(ctx.pairs)} is below the forward's pair "
+                                   f"count - the blend grid left some of the {short} work items unwalked")
 
         has_sh, has_col, _, _, _ = ctx.has
         g_colors, g_tau = pre["g_colors"], pre["g_tau"]

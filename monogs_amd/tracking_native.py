@@ -169,9 +169,9 @@ class NativeTracker:
         self.so_bucket = torch.empty(R, HW, dtype=torch.int32, device=dev)
         self.so_weights = torch.empty(R, HW, device=dev)
         self.so_accum = torch.zeros(9 * R * d + 4, device=dev)
-        # zero-filled once: the iteration's kernels keep the accumulators zero between calls
-        # (scratch_kept_zero), so no memset launches are needed per iteration
-        self.so_sketch_ws = torch.zeros(int(sizes.sketch_bytes), dtype=torch.uint8, device=dev)
+        # (so_accum is zero-filled once: the iteration's kernels keep the accumulators zero between calls -
+        # scratch_kept_zero - so no memset launches are needed per iteration; sketch_ws needs no initial state)
+        self.so_sketch_ws = torch.empty(int(sizes.sketch_bytes), dtype=torch.uint8, device=dev)
         self.lm_state = torch.tensor([initial_lambda, 0.0, 0.0, 0.0], device=dev)
         self._lm_initial = self.lm_state.clone()
         self.so_x = torch.zeros(8, device=dev)
@@ -198,7 +198,7 @@ class NativeTracker:
             so.base.fwd.shape.pair_capacity = self.args.fwd.shape.pair_capacity
             need = int(_cabi.workspace_sizes(so.base.fwd.shape).sketch_bytes)
             if self.so_sketch_ws.numel() < need:
-                self.so_sketch_ws = torch.zeros(need, dtype=torch.uint8, device=self.dev)
+                self.so_sketch_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
                 so.sketch_ws = self.so_sketch_ws.data_ptr()
         so.base.adam.T = self.args.adam.T
         so.base.best = self.args.best
@@ -273,8 +273,8 @@ class NativeTracker:
         lambda_ = initial_lambda, no previous second-order loss, and both sticky convergence flags cleared
         (once set they turn every later step() / step_second_order() into a no-op: a caller driving its own
         step loop over several frames calls this between frames; run() does).  The Adam moments are NOT
-        reset here: the reference builds a new optimiser per frame, so does whoever builds a tracker per
-        frame; reuse across frames goes through `reset_optimizer()`."""
+        reset here but by `reset_optimizer()`, which run() also calls by default: the reference builds a new
+        optimiser per frame."""
         self.reset_best()
         self.converged.zero_()
         if hasattr(self, "lm_state"):
@@ -368,7 +368,7 @@ class NativeTracker:
         self._matrices_fresh = False
 
     def run(self, max_iters=100, check_every=10, second_order_iters=0, use_first_order_best=True,
-            use_best_loss=True, render_best=True):
+            use_best_loss=True, render_best=True, reset_optimizer=True):
         """The reference's loop for one frame (slam_frontend.py:455-822): first-order iterations until
         converged or max_iters, then `second_order_iters` sketched LM iterations (enable_second_order
         first) unless the first order converged (its `break` leaves the whole loop, :623-626).  Every
@@ -382,8 +382,13 @@ class NativeTracker:
         convergence changes nothing), so the result does not depend on `check_every`.
         If ANY iteration overflowed the fixed pair capacity, pose, exposure, optimiser and best-iterate
         state are restored from the snapshot taken on entry, the workspaces grow and the run is
-        repeated: no truncated render ever reaches the result.  Returns the iterations enqueued."""
+        repeated: no truncated render ever reaches the result.  Returns the iterations enqueued.
+        `reset_optimizer` (default True): the reference builds a new torch.optim.Adam for every frame
+        (slam_frontend.py:453-455), so a tracker that is run() again starts from zero moments and step count 0,
+        exactly like a freshly built one; pass False to carry the moments over on purpose."""
         self.reset_frame()
+        if reset_optimizer:
+            self.reset_optimizer()
         keep = self._snapshot()
         for attempt in range(4):
             it = 0

@@ -356,6 +356,43 @@ def test_argument_validation(built):
             rotations=r.cpu())
 
 
+def test_backward_with_a_pair_count_bound_below_the_true_count_is_flagged(built):
+    """mgs_backward_args.pair_count_bound sizes the blend grid; a value below the forward's pair count would lose
+    work items silently.  The kernel flags it in counters[2] of the geom workspace, and the binding - which passes the
+    exact count - raises in debug mode (raster_settings.debug, as the upstream extension checks only then)."""
+    from monogs_amd import synthetic as S
+    from monogs_amd.rasterizer import GaussianRasterizer
+    dev = _dev()
+    sc = S.make_scene(3000, 160, 120, seed=2)
+    for debug in (False, True):
+        st = gpu_settings(sc.cam, sc.bg, dev)._replace(debug=debug)
+        m, s, r, o, sh = [t.to(dev).requires_grad_() for t in _inputs(sc)]
+        m2d = torch.zeros(3000, 3, device=dev, requires_grad=True)
+        img, radii, dep, opa, nt = GaussianRasterizer(st)(means3D=m, means2D=m2d, opacities=o, shs=sh, scales=s, rotations=r)
+        ctx = img.grad_fn                     # the autograd Function's ctx
+        geom = ctx.saved_tensors[12]
+        D = int(ctx.pairs)
+        assert D > 2000
+        from monogs_amd.rasterizer import _sizes
+        from monogs_amd import _cabi
+        N, W, H, deg, K, cap = ctx.shape_tuple
+        off = int(_sizes(_cabi.RasterShape(N, W, H, deg, K, cap, float(st.tanfovx), float(st.tanfovy), 1.0)).off_counters)
+        flag = lambda: int(geom[off + 8:off + 12].view(torch.int32).item())
+        img.sum().backward(retain_graph=True)
+        assert flag() == 0                    # the exact count covers every item
+        good = m.grad.clone()
+        m.grad = None
+        ctx.pairs = 64                        # a bound far below D: grid of 64 / 32 + T items
+        if debug:
+            with pytest.raises(RuntimeError, match="pair_count_bound"):
+                img.sum().backward()
+        else:
+            img.sum().backward()
+            # (the gradients themselves may even look right here: the unwalked items' pair records still hold what the
+            # complete backward above left in the per-stream scratch - which is why the flag exists)
+            assert flag() > 64 // 32 + 80
+
+
 def test_knn_dist2(built):
     from monogs_amd.knn import distCUDA2
     from oracle import torch_raster as O
