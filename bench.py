@@ -240,6 +240,55 @@ def bench_map_update(sc, dev):
     return out
 
 
+def bench_knn(dev):
+    """simple-knn's distCUDA2 (row a10; gaussian_model.py:185-191) at the sizes MonoGS calls it with: 640x480 / 64 =
+    4 800 points per keyframe (pcd_downsample 64), / 32 = 9 600 at initialisation, Replica 1200x680 / 64 = 12 750 and
+    / 32 = 25 500.  Exact tiled brute force: P (P - 1) distance evaluations per call.  HIP-event timed
+    around 20 calls (both launches of a call), scratch allocated outside the timed region."""
+    import ctypes as C
+    import torch
+    from monogs_amd import _cabi
+    lib = _cabi.lib()
+    g = torch.Generator().manual_seed(0)
+    out = {}
+    for P in (4800, 9600, 12750, 25500):
+        pts = (torch.rand(P, 3, generator=g) * torch.tensor([4.0, 3.0, 5.0])).to(dev)
+        res = torch.empty(P, device=dev)
+        scratch = torch.empty(int(lib.mgs_knn_scratch_bytes(P)), dtype=torch.uint8, device=dev)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+        def call():
+            _cabi.check(lib.mgs_knn_dist2(pts.data_ptr(), P, res.data_ptr(), scratch.data_ptr(), stream), "mgs_knn_dist2")
+        for _ in range(3):
+            call()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        out[str(P)] = {"knn_us": round(us, 1), "distance_evals_per_s": round(P * (P - 1) / (us * 1e-6), -6)}
+    return out
+
+
+def exchange_model(world, nbytes):
+    """DESIGN.md section 6's model of the per-iteration exchange (all-reduce(sum) of the flat fp32 buffer + all-reduce(max)
+    of the radii, `nbytes` in all) on the fully connected xGMI mesh (7 links x ~153 GB/s per GPU): a direct
+    reduce-scatter + all-gather moves nbytes / N per link and phase, a ring is bound by one link; both plus ~0.04 ms
+    of launch + synchronisation of the two collectives.  Printed beside the measured exchange_ms so that a SCALE record
+    judges itself."""
+    if world < 2:
+        return None
+    link = 153e9
+    direct = 2 * nbytes / world / link * 1e3
+    ring = 2 * (world - 1) / world * nbytes / link * 1e3
+    return {"direct_ms": round(direct + 0.04, 4), "ring_ms": round(ring + 0.04, 4), "bytes": int(nbytes),
+            "link_GBps": 153.0, "fixed_ms": 0.04,
+            "reading": "exchange_ms near direct_ms: RCCL used the mesh; near ring_ms: a ring - the remedy is a hand-rolled "
+                       "reduce-scatter / all-gather over the 7 links (DESIGN.md section 6)"}
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse(argv)
@@ -448,7 +497,7 @@ def main(argv=None):
         # HBM traffic per launch from the committed PMC pass of THIS round's kernels (rocprofv3
         # cannot run inside this process; profiles/collect.sh regenerates the file); only valid
         # for the default workload it was collected on
-        traffic, traffic_source = None, None
+        traffic, traffic_source, valu = None, None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         here = csrc_tree_hash()
         if (N, W, H) != (300_000, 640, 480):
@@ -459,6 +508,7 @@ def main(argv=None):
             tj = json.load(open(tpath))
             if tj.get("csrc_tree_hash") == here:
                 traffic = tj["bytes_per_launch"].get(dom)
+                valu = (tj.get("valu") or {}).get(dom)
                 traffic_source = (f"profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                   f"profiles/collect.sh on these kernel sources (csrc hash {here})")
             else:
@@ -468,7 +518,14 @@ def main(argv=None):
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0,
                     "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                     "traffic_source": traffic_source,
-                    "algorithmic_bytes": alg[dom], "avg_us": kernels[dom]}
+                    "algorithmic_bytes": alg[dom], "avg_us": kernels[dom],
+                    # what actually bounds the kernel (BASELINE defines `bound` / `frac` against HBM; the kernel is bound
+                    # by its VALU instruction stream): from the same PMC collection, same source hash, or null
+                    "valu_busy": None if valu is None else valu["valu_busy"],
+                    "valu_instructions": None if valu is None else valu["SQ_INSTS_VALU"],
+                    "valu_note": None if valu is None else
+                    "SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * kernel cycles): VALU issue cycles summed over the waves per SIMD "
+                    "cycle; ~1 = a SIMD always has a wave issuing VALU (a lone wave issues one per ~4.4 cycles)"}
 
     # ---- single-GPU extras: sustained rate and the default autograd engine ----
     extras = {}
@@ -550,6 +607,7 @@ def main(argv=None):
     if single and not args.no_slam:
         from monogs_amd.bench_legs import bench_slam_surrogate
         slam = bench_slam_surrogate(dev)
+    knn = bench_knn(dev) if (rank == 0 and not distributed and not args.lean) else None
 
     if rank == 0:
         out = {
@@ -570,11 +628,15 @@ def main(argv=None):
         if multi is not None:
             out["multi_gpu"] = multi
             out["exchange_ms"] = multi["exchange_ms"]
+            out["exchange_model"] = exchange_model(world, multi["exchange_bytes"])
+            if mapping_sharded is not None and "exchange_bytes" in mapping_sharded:
+                mapping_sharded["exchange_model"] = exchange_model(world, mapping_sharded["exchange_bytes"])
         if value_default_engine is not None:
             out["value_default_engine"] = round(value_default_engine, 2)
         out.update(extras)
         for k, v in (("tracking", tracking), ("map_update", map_update), ("mapping", mapping),
-                     ("mapping_replica", mapping_replica), ("mapping_sharded", mapping_sharded), ("slam", slam)):
+                     ("mapping_replica", mapping_replica), ("mapping_sharded", mapping_sharded), ("slam", slam),
+                     ("knn", knn)):
             if v is not None:
                 out[k] = v
         print(json.dumps(out), flush=True)

@@ -3,12 +3,20 @@
 // gaussian_splatting/scene/gaussian_model.py:185-191 with P = 2.4k..25k points.
 //
 // P is small, so the exact answer comes from a tiled brute force, parallelised over
-// (query block) x (candidate slice) so that even P = 2400 fills the chip: each workgroup
-// owns 256 query points (one per lane) and one slice of the candidates, candidates are
-// staged through LDS (coalesced loads, LDS broadcast reads), every lane keeps its three best
-// squared distances in registers (the insert is skipped wave-uniformly when no lane
-// improves), and a second small kernel merges the slices.  No sort, no tree, no atomics;
-// deterministic.
+// (query block) x (candidate slice) so that even P = 2400 fills the chip.  Round 5 rewrite (the first form - one
+// query per lane, candidates staged through LDS with two barriers per 256, a branchy insert - ran 111 / 540 us at
+// P = 4 800 / 25 500: one LDS round trip per candidate at 1.4 waves per SIMD, and a 19-workgroup merge):
+//   * a lane owns Q queries (1, 2 or 4 by P: more evaluations per candidate fetch at large P, more workgroups at
+//     small P) and keeps their three best squared distances in registers;
+//   * the candidate index is wave-uniform, so candidates come through the SCALAR path (s_load from the constant
+//     address space, eight candidates = 24 dwords per batch) - no LDS, no barrier, and the loads of the next batch are
+//     in flight under the arithmetic of this one;
+//   * two queries share packed arithmetic (v_pk_add / v_pk_mul / v_pk_fma_f32), every distance goes through a
+//     branch-free sorted insert (five v_min / v_max), and the self test (candidate == query) is only compiled into
+//     the batches that overlap the workgroup's own query range;
+//   * partial results are stored component-major ([slice][3][P]: coalesced), merged by a second small kernel.
+// No sort, no tree, no atomics; deterministic.  Fewer than four points: a missing neighbour counts as FLT_MAX
+// (what the absent extension's FLT_MAX-initialised best[3] yields [UPSTREAM-KNOWLEDGE]; oracle: dist2_knn3).
 #include <hip/hip_runtime.h>
 
 #include "../../include/monogs_raster.h"
@@ -18,83 +26,135 @@ namespace mgs {
 
 constexpr int kKnnBlock = 256;
 constexpr int kKnnMaxSlices = 64;
+constexpr int kKnnBatch = 8;         // candidates per scalar-load batch
+constexpr float kKnnInf = 3.4028235e38f;
+
+// (fminf / fmaxf make the compiler canonicalise an operand with a v_max_f32 v, v, v first.  Raw v_min_f32 / v_max_f32
+// through inline asm - five instructions per insert instead of up to eight - measured SLOWER on one box, back to back:
+// 34 / 61 / 77 / 215 us against 22 / 48 / 61 / 197 us at P = 4 800 / 9 600 / 12 750 / 25 500; the asm statements pin
+// the instruction order the scheduler otherwise interleaves across the four independent insert chains.)
+__device__ __forceinline__ float vmin(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ float vmax(float a, float b) { return fmaxf(a, b); }
 
 __device__ __forceinline__ void best3_insert(float d, float& b0, float& b1, float& b2) {
-  if (d < b2) {
-    if (d < b1) {
-      b2 = b1;
-      if (d < b0) { b1 = b0; b0 = d; } else { b1 = d; }
-    } else {
-      b2 = d;
-    }
-  }
+  // branch-free sorted insert (v_min / v_max issue at the cheap rate)
+  const float t0 = vmax(b0, d);
+  b0 = vmin(b0, d);
+  const float t1 = vmax(b1, t0);
+  b1 = vmin(b1, t0);
+  b2 = vmin(b2, t1);
 }
 
-static int knn_slices(int n) {
-  const int qb = (n + kKnnBlock - 1) / kKnnBlock;
-  int s = 1024 / qb;
-  if (s < 1) s = 1;
+struct KnnPlan { int q, qblocks, slices, slice_len; };
+
+static KnnPlan knn_plan(int n) {
+  KnnPlan p;
+  p.q = n >= 20000 ? 4 : (n >= 11000 ? 2 : 1);
+  p.qblocks = (n + kKnnBlock * p.q - 1) / (kKnnBlock * p.q);
+  // ~2 400 workgroups (~9 per CU) when the candidates allow it; a slice is a whole number of batches
+  int s = (2400 + p.qblocks - 1) / p.qblocks;
   if (s > kKnnMaxSlices) s = kKnnMaxSlices;
-  const int cb = qb;                       // candidate blocks of 256
-  if (s > cb) s = cb;
-  return s;
+  const int max_s = (n + 4 * kKnnBatch - 1) / (4 * kKnnBatch);      // at least four batches per slice
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  p.slice_len = ((n + s - 1) / s + kKnnBatch - 1) / kKnnBatch * kKnnBatch;
+  p.slices = (n + p.slice_len - 1) / p.slice_len;
+  return p;
 }
 
-__global__ __launch_bounds__(kKnnBlock) void k_knn_partial(const float* __restrict__ pts, int n,
-                                                           int slice_len, float* __restrict__ part) {
-  __shared__ float s_x[kKnnBlock], s_y[kKnnBlock], s_z[kKnnBlock];
+typedef const __attribute__((address_space(4))) float* cfloat_p;    // constant address space: uniform loads go scalar
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Q (even, or 1) queries per lane.  The squared distance of a PAIR of queries to one candidate is six packed
+// instructions (v_pk_add / v_pk_mul / v_pk_fma_f32 with the candidate's coordinates as scalar operands: two
+// evaluations for ~1.1x the issue time of one); every evaluation goes straight into the branch-free sorted insert.
+// (A first version kept a batch's distances and skipped the inserts when no lane improved: with 64 Q queries per wave
+// some lane nearly always does, and the 32 kept distances cost the kernel its occupancy - 168 VGPRs, 227 us at 25 500.)
+template <int Q>
+__global__ __launch_bounds__(kKnnBlock) void k_knn_partial(const float* __restrict__ pts, int n, int slice_len,
+                                                           float* __restrict__ part) {
+  constexpr int QP = (Q + 1) / 2;                                    // query pairs (Q = 1: the second half idles)
   const int tid = threadIdx.x;
-  const int q = blockIdx.x * kKnnBlock + tid;
+  const int q_first = blockIdx.x * (kKnnBlock * Q);                  // this workgroup's queries: [q_first, q_first + 256 Q)
   const int c0 = blockIdx.y * slice_len, c1 = min(n, c0 + slice_len);
-  float qx = 0.f, qy = 0.f, qz = 0.f;
-  if (q < n) { qx = pts[3 * q]; qy = pts[3 * q + 1]; qz = pts[3 * q + 2]; }
-  const float inf = 3.4028235e38f;
-  float b0 = inf, b1 = inf, b2 = inf;
-  for (int base = c0; base < c1; base += kKnnBlock) {
-    __syncthreads();
-    const int c = base + tid;
-    if (c < c1) { s_x[tid] = pts[3 * c]; s_y[tid] = pts[3 * c + 1]; s_z[tid] = pts[3 * c + 2]; }
-    __syncthreads();
-    const int nb = min(kKnnBlock, c1 - base);
-    for (int j = 0; j < nb; j++) {
-      const float dx = s_x[j] - qx, dy = s_y[j] - qy, dz = s_z[j] - qz;
-      const float d = dx * dx + dy * dy + dz * dz;
-      const bool better = d < b2 && (base + j) != q;
-      if (__builtin_amdgcn_ballot_w64(better) != 0ull) {
-        if (better) best3_insert(d, b0, b1, b2);
+  v2f qx[QP], qy[QP], qz[QP];
+  float b0[2 * QP], b1[2 * QP], b2[2 * QP];
+  int qi[2 * QP];
+#pragma unroll
+  for (int k = 0; k < 2 * QP; k++) {
+    qi[k] = k < Q ? q_first + k * kKnnBlock + tid : 0x7fffffff;
+    const int qc = min(qi[k], n - 1);
+    const float x = pts[3 * qc], y = pts[3 * qc + 1], z = pts[3 * qc + 2];
+    if (k & 1) { qx[k >> 1].y = x; qy[k >> 1].y = y; qz[k >> 1].y = z; }
+    else { qx[k >> 1].x = x; qy[k >> 1].x = y; qz[k >> 1].x = z; }
+    b0[k] = b1[k] = b2[k] = kKnnInf;
+  }
+  cfloat_p cp = (cfloat_p)pts;
+  // one candidate (index jc, coordinates wave-uniform); SELF: it may be one of this workgroup's queries
+  auto candidate = [&](int jc, float cx, float cy, float cz, auto self_tag) {
+    constexpr bool SELF = decltype(self_tag)::value;
+#pragma unroll
+    for (int p = 0; p < QP; p++) {
+      const v2f dx = v2f{cx, cx} - qx[p], dy = v2f{cy, cy} - qy[p], dz = v2f{cz, cz} - qz[p];
+      v2f d = dx * dx;
+      d = __builtin_elementwise_fma(dy, dy, d);
+      d = __builtin_elementwise_fma(dz, dz, d);
+      float d0 = d.x, d1 = d.y;
+      if (SELF) {
+        if (jc == qi[2 * p]) d0 = kKnnInf;
+        if (jc == qi[2 * p + 1]) d1 = kKnnInf;
       }
+      best3_insert(d0, b0[2 * p], b1[2 * p], b2[2 * p]);
+      if (2 * p + 1 < Q) best3_insert(d1, b0[2 * p + 1], b1[2 * p + 1], b2[2 * p + 1]);
     }
+  };
+  auto batch = [&](int j, auto self_tag) {
+    float c[3 * kKnnBatch];
+#pragma unroll
+    for (int i = 0; i < 3 * kKnnBatch; i++) c[i] = cp[3 * (size_t)j + i];        // wave-uniform: s_load_dwordx8 x 3
+#pragma unroll
+    for (int i = 0; i < kKnnBatch; i++) candidate(j + i, c[3 * i], c[3 * i + 1], c[3 * i + 2], self_tag);
+  };
+  const int full_end = c0 + max(c1 - c0, 0) / kKnnBatch * kKnnBatch;
+  for (int j = c0; j < full_end; j += kKnnBatch) {
+    if (j + kKnnBatch > q_first && j < q_first + kKnnBlock * Q) batch(j, std::true_type{});     // wave-uniform
+    else batch(j, std::false_type{});
   }
-  if (q < n) {
-    float* o = part + ((size_t)blockIdx.y * n + q) * 3;
-    o[0] = b0; o[1] = b1; o[2] = b2;
-  }
+  for (int j = full_end; j < c1; j++)         // tail of the last slice: fewer than a batch
+    candidate(j, cp[3 * (size_t)j], cp[3 * (size_t)j + 1], cp[3 * (size_t)j + 2], std::true_type{});
+#pragma unroll
+  for (int k = 0; k < Q; k++)
+    if (qi[k] < n) {
+      float* o = part + (size_t)blockIdx.y * 3 * n + qi[k];       // [slice][3][n]
+      o[0] = b0[k]; o[n] = b1[k]; o[2 * (size_t)n] = b2[k];
+    }
 }
 
 __global__ __launch_bounds__(kKnnBlock) void k_knn_merge(const float* __restrict__ part, int n,
                                                          int slices, float* __restrict__ out) {
   const int q = blockIdx.x * kKnnBlock + threadIdx.x;
   if (q >= n) return;
-  const float inf = 3.4028235e38f;
-  float b0 = inf, b1 = inf, b2 = inf;
+  float b0 = kKnnInf, b1 = kKnnInf, b2 = kKnnInf;
   for (int s = 0; s < slices; s++) {
-    const float* p = part + ((size_t)s * n + q) * 3;
-    best3_insert(p[0], b0, b1, b2);
-    best3_insert(p[1], b0, b1, b2);
-    best3_insert(p[2], b0, b1, b2);
+    const float* p = part + (size_t)s * 3 * n + q;
+    const float x = p[0], y = p[n], z = p[2 * (size_t)n];
+    best3_insert(x, b0, b1, b2);
+    best3_insert(y, b0, b1, b2);
+    best3_insert(z, b0, b1, b2);
   }
   out[q] = (b0 + b1 + b2) / 3.0f;
 }
 
-uint64_t knn_scratch_bytes(int n) { return (uint64_t)knn_slices(n) * (uint64_t)n * 3 * sizeof(float) + 256; }
+uint64_t knn_scratch_bytes(int n) { return (uint64_t)kKnnMaxSlices * (uint64_t)n * 3 * sizeof(float) + 256; }
 
 int launch_knn(const float* pts, int n, float* out, void* scratch, hipStream_t st) {
-  const int slices = knn_slices(n);
-  const int qb = (n + kKnnBlock - 1) / kKnnBlock;
-  const int slice_len = ((n + slices - 1) / slices + kKnnBlock - 1) / kKnnBlock * kKnnBlock;
+  const KnnPlan p = knn_plan(n);
   float* part = (float*)scratch;
-  launch("knn_partial", k_knn_partial, dim3(qb, slices), dim3(kKnnBlock), st, pts, n, slice_len, part);
-  launch("knn_merge", k_knn_merge, dim3(qb), dim3(kKnnBlock), st, (const float*)part, n, slices, out);
+  const dim3 grid(p.qblocks, p.slices), block(kKnnBlock);
+  if (p.q == 4) launch("knn_partial", k_knn_partial<4>, grid, block, st, pts, n, p.slice_len, part);
+  else if (p.q == 2) launch("knn_partial", k_knn_partial<2>, grid, block, st, pts, n, p.slice_len, part);
+  else launch("knn_partial", k_knn_partial<1>, grid, block, st, pts, n, p.slice_len, part);
+  launch("knn_merge", k_knn_merge, dim3((n + kKnnBlock - 1) / kKnnBlock), block, st, (const float*)part, n, p.slices, out);
   return launches_ok() ? MGS_OK : MGS_ERR_LAUNCH;
 }
 

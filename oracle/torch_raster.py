@@ -404,7 +404,11 @@ def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotation
 
 def dist2_knn3(points: torch.Tensor) -> torch.Tensor:
     """Oracle of simple_knn._C.distCUDA2 (gaussian_model.py:185-191): mean squared
-    distance to the 3 nearest other points (exact). O(P^2), chunked."""
+    distance to the 3 nearest other points (exact). O(P^2), chunked.
+    Fewer than four points [UPSTREAM-KNOWLEDGE, unpinned: the simple-knn submodule is absent]: the extension keeps
+    its three best distances initialised to FLT_MAX and returns (best[0] + best[1] + best[2]) / 3 in fp32, so a
+    missing neighbour counts as FLT_MAX - P = 3 gives (d1 + d2 + FLT_MAX) / 3 ~ 1.1e38, P <= 2 overflows to inf
+    (MonoGS never gets there: a keyframe contributes thousands of points)."""
     P = points.shape[0]
     out = torch.empty(P, dtype=points.dtype)
     p64 = points.double()
@@ -413,6 +417,10 @@ def dist2_knn3(points: torch.Tensor) -> torch.Tensor:
         d2 = ((q[:, None, :] - p64[None, :, :]) ** 2).sum(-1)
         d2[torch.arange(q.shape[0]), torch.arange(s, s + q.shape[0])] = float("inf")
         k = min(3, P - 1)
-        best = torch.topk(d2, k, dim=1, largest=False).values
-        out[s:s + 2048] = (best.sum(1) / 3.0).to(points.dtype)
+        best = torch.topk(d2, k, dim=1, largest=False).values if k > 0 else d2.new_zeros(q.shape[0], 0)
+        if k < 3:      # missing neighbours count as FLT_MAX, summed in fp32 in the order best[0] + best[1] + best[2]
+            b32 = torch.cat((best.float(), torch.full((q.shape[0], 3 - k), 3.4028234663852886e38)), 1)
+            out[s:s + 2048] = (((b32[:, 0] + b32[:, 1]) + b32[:, 2]) / 3.0).to(points.dtype)
+        else:
+            out[s:s + 2048] = (best.sum(1) / 3.0).to(points.dtype)
     return out

@@ -94,3 +94,25 @@ if len(sys.argv) > 2 and sys.argv[2] == "sq":
             for c, vals in sorted(v.items()):
                 fh.write(f"  {c:28s} {sum(vals) / len(vals):16.0f}  (avg of {len(vals)} launches)\n")
     print(open(f"{out}/sq_counters_per_kernel.txt").read())
+    # VALU figures of the timed kernels into pmc_traffic.json (bench.py quotes roofline.valu_busy from there, under the
+    # same source hash as the traffic).  valu_busy = SQ_ACTIVE_INST_VALU * 4 / (SIMDs * kernel cycles): the counter adds
+    # up, over all waves, the (quad-)cycles a wave spent issuing VALU instructions - a lone wave issues one per ~4.4
+    # cycles, a SIMD with 6-8 resident waves retires one per 1.2-2.3 cycles (profiles/r02_valu_issue_microbench.txt),
+    # so 1.0 means "one wave's worth of back-to-back VALU issue per SIMD all the time", not "the pipe is full".
+    # Kernel cycles = rocprofv3 --stats duration * 2.4 GHz (nominal clock), 1024 SIMDs.
+    dur = {short(r["Name"]): float(r["AverageNs"]) / 1e3 for r in rows}
+    tj = json.load(open(f"{out}/pmc_traffic.json"))
+    tj["valu"] = {}
+    for k, v in sq.items():
+        b = bench_name(k)
+        if b is None or k not in dur or "SQ_ACTIVE_INST_VALU" not in v:
+            continue
+        act = sum(v["SQ_ACTIVE_INST_VALU"]) / len(v["SQ_ACTIVE_INST_VALU"])
+        insts = sum(v["SQ_INSTS_VALU"]) / len(v["SQ_INSTS_VALU"]) if "SQ_INSTS_VALU" in v else None
+        cycles = dur[k] * 2400.0
+        tj["valu"][b] = {"SQ_ACTIVE_INST_VALU": int(act), "SQ_INSTS_VALU": None if insts is None else int(insts),
+                         "avg_us": round(dur[k], 2), "valu_busy": round(act * 4 / (1024 * cycles), 3),
+                         "cycles_per_valu_per_simd": None if not insts else round(1024 * cycles / insts, 2)}
+    tj["valu_note"] = ("valu_busy = SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * duration * 2.4 GHz): wave-issue cycles summed over "
+                       "the waves per SIMD cycle (a lone wave: one VALU per ~4.4 cycles; a full SIMD retires one per 1.2-2.3)")
+    json.dump(tj, open(f"{out}/pmc_traffic.json", "w"), indent=1)

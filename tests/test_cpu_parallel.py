@@ -193,6 +193,22 @@ def _mapping_worker_uneven(rank, world, port, ret):
     bucket = FlatGradBucket([gauss._xyz, gauss._features_dc, gauss._opacity, gauss._scaling, gauss._rotation])
     st = _run_mapping(gauss, local, [v.uid for v in local], bucket, pose_window=5)
     st["n_local"] = torch.tensor(len(local))
+    # prune iteration (slam_backend.py:259-265): every rank learns the occ-aware visibility of every WINDOW view
+    # (the first 8; the two old keyframes are not part of n_obs) - round k gathers the k-th local view of each rank
+    from monogs_amd.parallel import all_gather_visibility
+    N = gauss._xyz.shape[0]
+    n_obs = torch.zeros(N, dtype=torch.int32)
+    for k in range((8 + world - 1) // world):
+        uid = k * world + rank
+        nt = torch.zeros(N, dtype=torch.int32)
+        if uid < 8:
+            with torch.no_grad():
+                nt = _oracle_render(views[uid], gauss, None, torch.zeros(3))["n_touched"].to(torch.int32)
+        rows = all_gather_visibility(nt)
+        for r in range(world):
+            if k * world + r < 8:
+                n_obs += rows[r].to(torch.int32)
+    st["n_obs"] = n_obs
     ret[rank] = {k: v.numpy() for k, v in st.items()}
     dist.destroy_process_group()
 
@@ -223,3 +239,37 @@ def test_sharded_mapping_step_matches_single_process_world4_uneven_split():
     # keyframe 0 is never moved (update_pose skips uid 0, slam_backend.py:328-332)
     from monogs_amd.parallel import view_pose
     np.testing.assert_array_equal(ret[0]["T0"], view_pose(0).numpy())
+
+
+# ---------------------------------------------------------------------------------------------
+# ... and on EIGHT ranks, the node BASELINE config 5 names: the 8 window views one per rank and the two old keyframes a
+# second view on ranks 0 and 1 (2 / 2 / 1 / 1 / 1 / 1 / 1 / 1), the placement DESIGN.md section 6's model prices at 4.3x.
+def test_sharded_mapping_step_matches_single_process_world8_config5_split():
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    gauss, views = _mapping_fixture(10)
+    single = _run_mapping(gauss, views, None, None, pose_window=5)
+    with torch.no_grad():       # n_obs of the stepped map over the 8 window views, single process
+        n_obs = sum((_oracle_render(views[u], gauss, None, torch.zeros(3))["n_touched"] > 0).int() for u in range(8))
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + ((os.getpid() + 389) % 500)
+    mp.spawn(_mapping_worker_uneven, args=(8, port, ret), nprocs=8, join=True)
+    assert [int(ret[r]["n_local"]) for r in range(8)] == [2, 2, 1, 1, 1, 1, 1, 1]
+    for rank in range(8):
+        got = ret[rank]
+        for k in ("xyz", "scaling", "opacity", "rot", "fdc", "grad_norm", "denom", "radii"):
+            np.testing.assert_allclose(got[k], single[k].numpy(), rtol=3e-4, atol=3e-6, err_msg=f"rank {rank} {k}")
+        for uid in range(10):
+            if uid % 8 == rank:
+                for k in (f"T{uid}", f"a{uid}", f"tau{uid}"):
+                    np.testing.assert_allclose(got[k], single[k].numpy(), rtol=3e-4, atol=3e-6, err_msg=f"rank {rank} {k}")
+        # the prune iteration's observation counts: identical on every rank, equal to the single-process count
+        # (a Gaussian exactly at a visibility cut-off may flip with the 3e-4 agreement of the stepped maps)
+        assert int(np.abs(got["n_obs"] - n_obs.numpy()).sum()) <= 2, rank
+        np.testing.assert_array_equal(got["n_obs"], ret[0]["n_obs"])
+    # the regulariser was added once (rank 0 only): a map stepped with it 8 times would not match `single` above.
+    # update_pose gate on the GLOBAL window position: view 4 (rank 4's only view, < pose_window) applied,
+    # view 5 (rank 5) and the old keyframes 8, 9 (second views of ranks 0, 1) keep their stepped deltas
+    assert np.abs(ret[4]["tau4"]).max() == 0 and np.abs(ret[5]["tau5"]).max() > 0
+    assert np.abs(ret[0]["tau8"]).max() > 0 and np.abs(ret[1]["tau9"]).max() > 0

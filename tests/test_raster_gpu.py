@@ -402,6 +402,15 @@ def test_knn_dist2(built):
         got = distCUDA2(pts.to(_dev())).cpu()
         want = O.dist2_knn3(pts)
         assert torch.allclose(got, want, rtol=1e-4, atol=1e-7), P
+    # fewer than four points: a missing neighbour counts as FLT_MAX (see the oracle's docstring)
+    for P in (1, 2, 3):
+        pts = torch.rand(P, 3, generator=g)
+        got = distCUDA2(pts.to(_dev())).cpu()
+        want = O.dist2_knn3(pts)
+        assert got.shape == (P,) and torch.equal(torch.isinf(got), torch.isinf(want)), (P, got, want)
+        fin = torch.isfinite(want)
+        assert torch.allclose(got[fin], want[fin], rtol=1e-6) and bool((got > 1e37).all()), (P, got, want)
+    assert distCUDA2(torch.zeros(0, 3, device=_dev())).shape == (0,)
 
 
 # ---------------------------------------------------------------------------------------
