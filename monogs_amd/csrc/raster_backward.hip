@@ -207,7 +207,7 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
   unsigned int lastp = 0u;
   float g0[4], g1[4], g2[4], gd[4], T[4], gS[4];
   const float bg0 = P.bg[0], bg1 = P.bg[1], bg2 = P.bg[2];
-  const float* ck = (base > 0) ? P.ckpt + (size_t)item * (5 * 256) : nullptr;
+  const float* ck = (MGS_ABL_CKPT && base > 0) ? P.ckpt + (size_t)item * (5 * 256) : nullptr;
   // Last list position that still contributes anywhere in each quadrant (stored by the forward's
   // quadrant waves; a quadrant outside the image was never rendered).  A splat behind it cannot
   // contribute in that quadrant - the forward had stopped visiting the saturated quadrant - so its
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
       // wave-uniform; buffer store: the record's offset is a scalar (soffset), the lane adds its 32-bit byte
       // offset, and a lane without a dword has an offset beyond the buffer's extent, which drops its store
       // (no per-lane 64-bit address, no exec masking)
-      if (sj >= 0)
+      if (MGS_ABL_PAIR && sj >= 0)
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(wextra ? eres : mres), pair_rsrc, wofs4, sj * (kPairStride * 4), 0);
       written |= 1ull << j;
     }
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(64, SKETCH ? (JONLY ? 4 : 3) : 6) void k_blend_bwd(
         if (slot >= P.cap) slot = -1;
       }
       if (!dead) {
-        const float4* src = reinterpret_cast<const float4*>(P.rec + id);
+        const float4* src = reinterpret_cast<const float4*>(P.rec + MGS_ABL_REC(id));
         const float4 qa = src[0];     // 16 + 12 + 12 B: no dead components (see k_blend_fwd)
         const float3 qb = *reinterpret_cast<const float3*>(src + 1), q2 = *reinterpret_cast<const float3*>(src + 2);
         s_r0[lane] = make_float4(qa.x, qa.y, -0.5f * kLog2eB * qb.x, -kLog2eB * qb.y);

@@ -863,7 +863,7 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
   // (ids default to 0, a valid record, so the record loads need no branch)
   unsigned int id_n1 = fwd_load_id(P, start, n, kSeg + lane);
   unsigned int cid = fwd_load_id(P, start, n, lane);
-  const float4* src0 = reinterpret_cast<const float4*>(P.rec + cid);
+  const float4* src0 = reinterpret_cast<const float4*>(P.rec + MGS_ABL_REC(cid));
   // 16 + 12 + 12 bytes: the fourth dwords of the conic and colour rows are not used here, and a
   // dead component of a wide load is a free register to the allocator - anything it parks there
   // has to wait for the load to land (it cost one memory round trip per segment).
@@ -881,7 +881,7 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
   float mid_T = 0.f;
   v2f mid_01 = {0.f, 0.f}, mid_2D = {0.f, 0.f};
   auto flush_mid = [&]() {
-    if (sg_mid >= 0 && sg_mid < P.max_segs) {
+    if (MGS_ABL_CKPT && sg_mid >= 0 && sg_mid < P.max_segs) {
       float* ck = P.ckpt + (size_t)sg_mid * (5 * 256);
       reinterpret_cast<float4*>(ck)[ptile] = make_float4(mid_T, mid_01.x, mid_01.y, mid_2D.x);
       ck[1024 + ptile] = mid_2D.y;
@@ -924,7 +924,7 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
     }
     if (base > 0 && base % kItem == 0) {   // checkpoint: state in front of this backward item
       const int sg = seg0 + base / kItem;
-      if (sg < P.max_segs) {
+      if (MGS_ABL_CKPT && sg < P.max_segs) {
         float* ck = P.ckpt + (size_t)sg * (5 * 256);
         reinterpret_cast<float4*>(ck)[ptile] = make_float4(fabsf(T), C01.x, C01.y, C2D.x);
         ck[1024 + ptile] = C2D.y;
@@ -932,7 +932,7 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
     }
     // loads of the NEXT segment (records) and of the one after it (ids)
     const unsigned int nid = id_n1;
-    const float4* src1 = reinterpret_cast<const float4*>(P.rec + nid);
+    const float4* src1 = reinterpret_cast<const float4*>(P.rec + MGS_ABL_REC(nid));
     const float4 na = src1[0];
     const float3 nb4 = *reinterpret_cast<const float3*>(src1 + 1), nc = *reinterpret_cast<const float3*>(src1 + 2);
     id_n1 = fwd_load_id(P, start, n, base + 2 * kSeg + lane);

@@ -7,6 +7,27 @@
 #include "../../include/monogs_raster.h"
 #include "raster_math.h"
 
+// Traffic ablations (variant builds of profiles/tools/build_variant.sh only; the product is built without them):
+//   -DMGS_ABL_REC0    every splat-record gather of the blend kernels reads record 0  -> what the gathers fetch
+//   -DMGS_ABL_NOCKPT  the forward writes no blend checkpoints, the backward reads none -> what the checkpoints move
+//   -DMGS_ABL_NOPAIR  the backward stores no pair records                              -> what the pair records write
+// (results are wrong by construction; only durations and FETCH_SIZE / WRITE_SIZE of such a build mean anything)
+#ifdef MGS_ABL_REC0
+#define MGS_ABL_REC(id) 0u
+#else
+#define MGS_ABL_REC(id) (id)
+#endif
+#ifdef MGS_ABL_NOCKPT
+#define MGS_ABL_CKPT false
+#else
+#define MGS_ABL_CKPT true
+#endif
+#ifdef MGS_ABL_NOPAIR
+#define MGS_ABL_PAIR false
+#else
+#define MGS_ABL_PAIR true
+#endif
+
 namespace mgs {
 
 // One struct carries everything a forward or backward kernel may need; it is passed

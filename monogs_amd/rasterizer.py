@@ -10,6 +10,7 @@ autograd bookkeeping only.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import NamedTuple, Optional
 
 import torch
@@ -107,6 +108,21 @@ def _host_counter(dev_index):
     return ring["buf"][2 * i:2 * i + 2], ring["ev"][i]      # [0] = D, [1] = pairs in the fullest tile
 
 
+_SPIN_QUERIES = int(os.environ.get("MGS_EVENT_SPIN", "400"))
+
+
+def _wait_event(ev):
+    """Wait for the pair-count event with a bounded busy-poll first: the host learns D a few microseconds after the
+    GPU wrote it instead of after a blocking wait's wake-up (tens of microseconds on a virtualised host), and what is
+    left of the step's host work - loss and backward enqueue - has to fit under the ~100 us the GPU still needs for
+    the blend stage.  Falls back to the blocking wait after ~0.5 ms of polling (MGS_EVENT_SPIN=0: always block)."""
+    q = ev.query
+    for _ in range(_SPIN_QUERIES):
+        if q():
+            return
+    ev.synchronize()
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
@@ -181,39 +197,46 @@ class _RasterizeGaussians(torch.autograd.Function):
         prepared = None
         needs_grad = any(ctx.needs_input_grad[:10])
         saved_small = (means3D_c, sh_c, col_c, op_c, sc_c, rot_c, cov_c, view, proj, praw, campos, bg, geom)
-        if hint:
-            bins = run_blend(int(hint))      # optimistic: overlaps the host wait below
-            if needs_grad:                   # ... and so does the preparation of the backward
-                prepared = _RasterizeGaussians._prepare_backward(
-                    saved_small + (bins,), st, (N, W, H, int(st.sh_degree), K, int(hint)),
-                    (int(sketch_mode), int(sketch_dim), int(stack_dim)))
-        ev.synchronize()
-        D = int(host_cnt[0].item())
-        _tile_max_hint[dev.index] = int(host_cnt[1].item())
-        if bins is None or D > shape.pair_capacity:
-            retried = bins is not None
-            prepared = None                  # sized for the old capacity
-            bins = run_blend(_round_cap(D))
-        # high-water mark with slow decay, so one unusually heavy view does not pin memory forever
-        _capacity_hint[dev.index] = max(_round_cap(D), int(shape.pair_capacity * 0.97) // 1024 * 1024)
-        last_stats.update(pairs=D, capacity=int(shape.pair_capacity), retried=retried, N=N)
-
-        ctx.pairs = D
+        # Everything of the bookkeeping that does not depend on the pair count happens BEFORE the wait for it: the GPU
+        # is busy with the projection stage anyway, and what runs after the wait - the caller's loss and the backward
+        # enqueue - has to fit under the ~100 us the GPU still needs for the blend stage.
         ctx.raster_settings = st
-        ctx.prepared = prepared
-        ctx.shape_tuple = (N, W, H, int(st.sh_degree), K, int(shape.pair_capacity))
         ctx.sketch = (int(sketch_mode), int(sketch_dim), int(stack_dim))
         ctx.sketch_indices = sketch_indices
         ctx.repeat_iter = 0
         ctx.op_shape = tuple(opacities.shape)
         ctx.has = (sh_c is not None, col_c is not None, sc_c is not None, rot_c is not None,
                    cov_c is not None)
-        ctx.save_for_backward(means3D_c, sh_c, col_c, op_c, sc_c, rot_c, cov_c, view, proj, praw,
-                              campos, bg, geom, bins)
         ctx.mark_non_differentiable(radii, n_touched)
         # undefined output gradients stay None (otherwise autograd fills three zero tensors -
         # two of them N ints - before every backward)
         ctx.set_materialize_grads(False)
+        saved = False
+        if hint:
+            bins = run_blend(int(hint))      # optimistic: overlaps the host wait below
+            if needs_grad:                   # ... and so does the preparation of the backward
+                prepared = _RasterizeGaussians._prepare_backward(
+                    saved_small + (bins,), st, (N, W, H, int(st.sh_degree), K, int(hint)),
+                    (int(sketch_mode), int(sketch_dim), int(stack_dim)))
+            ctx.save_for_backward(*saved_small, bins)
+            saved = True
+        _wait_event(ev)
+        D, tile_max = host_cnt.tolist()
+        _tile_max_hint[dev.index] = tile_max
+        if bins is None or D > shape.pair_capacity:
+            retried = bins is not None
+            prepared = None                  # sized for the old capacity
+            bins = run_blend(_round_cap(D))
+            saved = False
+        # high-water mark with slow decay, so one unusually heavy view does not pin memory forever
+        cap = int(shape.pair_capacity)
+        _capacity_hint[dev.index] = max(_round_cap(D), int(cap * 0.97) // 1024 * 1024)
+        last_stats.update(pairs=D, capacity=cap, retried=retried, N=N)
+        ctx.pairs = D
+        ctx.prepared = prepared
+        ctx.shape_tuple = (N, W, H, int(st.sh_degree), K, cap)
+        if not saved:
+            ctx.save_for_backward(*saved_small, bins)
         return color, radii, depth, opacity, n_touched
 
     @staticmethod
