@@ -827,9 +827,17 @@ __global__ __launch_bounds__(64, 6) void k_blend_fwd(KP P) {
   MGS_STAMP_SCOPE;
   // per staged splat 48 B: (a0, a1, a2, A) (B, C, opacity, -) (r, g, b, depth)
   __shared__ float4 s_rec[kSeg * 3];
+#ifdef MGS_FWD_BLOCKS
+  // experiment: an XCD takes 4x4 blocks of tiles (launch-order index -> tile through tile_from_block_order)
+  const int item0 = xcd_remap<64>(blockIdx.x);
+  if (item0 >= 4 * P.T) return;
+  const int tile = tile_from_block_order(item0 >> 2, P.grid_x, P.grid_y), quad = item0 & 3, lane = threadIdx.x;
+  const int item = 4 * tile + quad;
+#else
   const int item = xcd_remap<kFwdChunk>(blockIdx.x);
   if (item >= 4 * P.T) return;
   const int tile = item >> 2, quad = item & 3, lane = threadIdx.x;
+#endif
   const int tx = tile % P.grid_x, ty = tile / P.grid_x;
   const int qx0 = tx * kTile + 8 * (quad & 1), qy0 = ty * kTile + 8 * (quad >> 1);
   if (qx0 >= P.W || qy0 >= P.H) {                        // quadrant outside the image
@@ -1198,8 +1206,13 @@ int launch_forward_blend(const KP& P, hipStream_t st) {
     launch("tile_sort", k_tile_sort_reg<false>, dim3(P.T), dim3(256), st, P);
     if (P.big_pass) launch("tile_sort_big", k_tile_sort<4096, 1024, false, 1024>, dim3(min(P.T, 512)), dim3(1024), st, P);
   }
-  if (P.obj.on) launch("blend_fwd", k_blend_fwd<true>, dim3(grid_pad(4 * P.T, kFwdChunk)), dim3(64), st, P);
-  else launch("blend_fwd", k_blend_fwd<false>, dim3(grid_pad(4 * P.T, kFwdChunk)), dim3(64), st, P);
+#ifdef MGS_FWD_BLOCKS
+  constexpr int kFwdGridChunk = 64;
+#else
+  constexpr int kFwdGridChunk = kFwdChunk;
+#endif
+  if (P.obj.on) launch("blend_fwd", k_blend_fwd<true>, dim3(grid_pad(4 * P.T, kFwdGridChunk)), dim3(64), st, P);
+  else launch("blend_fwd", k_blend_fwd<false>, dim3(grid_pad(4 * P.T, kFwdGridChunk)), dim3(64), st, P);
   return check_launch();
 }
 

@@ -141,6 +141,18 @@ struct KB {   // backward extras
 // RESULT to [0, 1] is the same function and folds into v_exp_f32's clamp output modifier.
 __device__ __forceinline__ float exp2_sat(float x) { return __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(x), 0.f, 1.f); }
 
+// Launch-order index -> row-major tile id when the tiles are walked in 4x4 BLOCKS (bands of four tile rows, inside a
+// band column blocks of four tiles, inside a block row-major; the last band / column block may be narrower).  A
+// bijection of [0, gx * gy).  Used by the forward-blend placement experiment (-DMGS_FWD_BLOCKS).
+__host__ __device__ inline int tile_from_block_order(int i, int gx, int gy) {
+  const int band = i / (4 * gx), r = i - band * 4 * gx;
+  const int h = min(4, gy - 4 * band);                 // rows of this band (1..4)
+  const int c = r / (4 * h), r2 = r - c * 4 * h;       // column block, position inside it
+  const int wc = min(4, gx - 4 * c);                   // its width (1..4)
+  const int ty = 4 * band + r2 / wc, tx = 4 * c + r2 % wc;
+  return ty * gx + tx;
+}
+
 template <int CHUNK>
 __device__ __forceinline__ int xcd_remap(int bid) {
   const int xcd = bid & 7, slot = bid >> 3;
