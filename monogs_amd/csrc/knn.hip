@@ -29,15 +29,13 @@ constexpr int kKnnMaxSlices = 64;
 constexpr int kKnnBatch = 8;         // candidates per scalar-load batch
 constexpr float kKnnInf = 3.4028235e38f;
 
-// (fminf / fmaxf make the compiler canonicalise an operand with a v_max_f32 v, v, v first.  Raw v_min_f32 / v_max_f32
-// through inline asm - five instructions per insert instead of up to eight - measured SLOWER on one box, back to back:
-// 34 / 61 / 77 / 215 us against 22 / 48 / 61 / 197 us at P = 4 800 / 9 600 / 12 750 / 25 500; the asm statements pin
-// the instruction order the scheduler otherwise interleaves across the four independent insert chains.)
+// Branch-free sorted insert.  (fminf / fmaxf make the compiler canonicalise an operand with a v_max_f32 v, v, v first;
+// raw v_min_f32 / v_max_f32 through inline asm - five instructions per insert instead of up to eight - measured 1-5 %
+// SLOWER back to back on one box, 22.1 / 48.9 / 63.8 / 205 us against 21.8 / 48.0 / 61.2 / 195 us: not taken.)
 __device__ __forceinline__ float vmin(float a, float b) { return fminf(a, b); }
 __device__ __forceinline__ float vmax(float a, float b) { return fmaxf(a, b); }
 
 __device__ __forceinline__ void best3_insert(float d, float& b0, float& b1, float& b2) {
-  // branch-free sorted insert (v_min / v_max issue at the cheap rate)
   const float t0 = vmax(b0, d);
   b0 = vmin(b0, d);
   const float t1 = vmax(b1, t0);
@@ -51,8 +49,11 @@ static KnnPlan knn_plan(int n) {
   KnnPlan p;
   p.q = n >= 20000 ? 4 : (n >= 11000 ? 2 : 1);
   p.qblocks = (n + kKnnBlock * p.q - 1) / (kKnnBlock * p.q);
-  // ~2 400 workgroups (~9 per CU) when the candidates allow it; a slice is a whole number of batches
-  int s = (2400 + p.qblocks - 1) / p.qblocks;
+  // As many workgroups as are resident AT ONCE (256 CUs x waves per SIMD: 78 VGPRs -> 6 at Q = 4, else 8), not more: the
+  // workgroups all take the same time, so a second, nearly empty round would double the kernel's duration (it did:
+  // 2 432 workgroups at P = 9 600 and 1 600 at 25 500 against 2 048 / 1 536 slots).  A slice is a whole number of batches.
+  const int resident = 256 * (p.q == 4 ? 6 : 8);
+  int s = resident / p.qblocks;
   if (s > kKnnMaxSlices) s = kKnnMaxSlices;
   const int max_s = (n + 4 * kKnnBatch - 1) / (4 * kKnnBatch);      // at least four batches per slice
   if (s > max_s) s = max_s;
@@ -135,12 +136,39 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_merge(const float* __restrict
   const int q = blockIdx.x * kKnnBlock + threadIdx.x;
   if (q >= n) return;
   float b0 = kKnnInf, b1 = kKnnInf, b2 = kKnnInf;
-  for (int s = 0; s < slices; s++) {
+  // The loads of four slices are in flight together (the loop MUST be unrolled: rolled, it is one memory round trip
+  // per slice - 60 of them at P = 4 800 - and the merge, not the distance pass, sets the call's time: 34 instead
+  // of 22 us; a tail loop takes the remainder)
+  constexpr int U = 4;
+  int s = 0;
+  for (; s + U <= slices; s += U) {
+    float v[3 * U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const float* p = part + (size_t)(s + u) * 3 * n + q;
+      v[3 * u] = p[0]; v[3 * u + 1] = p[n]; v[3 * u + 2] = p[2 * (size_t)n];
+    }
+#pragma unroll
+    for (int i = 0; i < 3 * U; i++) {
+      const float t0 = fmaxf(b0, v[i]);
+      b0 = fminf(b0, v[i]);
+      const float t1 = fmaxf(b1, t0);
+      b1 = fminf(b1, t0);
+      b2 = fminf(b2, t1);
+    }
+  }
+  for (; s < slices; s++) {
     const float* p = part + (size_t)s * 3 * n + q;
     const float x = p[0], y = p[n], z = p[2 * (size_t)n];
-    best3_insert(x, b0, b1, b2);
-    best3_insert(y, b0, b1, b2);
-    best3_insert(z, b0, b1, b2);
+    const float vv[3] = {x, y, z};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const float t0 = fmaxf(b0, vv[i]);
+      b0 = fminf(b0, vv[i]);
+      const float t1 = fmaxf(b1, t0);
+      b1 = fminf(b1, t0);
+      b2 = fminf(b2, t1);
+    }
   }
   out[q] = (b0 + b1 + b2) / 3.0f;
 }
