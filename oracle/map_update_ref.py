@@ -138,3 +138,13 @@ def add_densification_stats(grad_accum, denom, viewspace_grad, update_filter):
     ga[update_filter] += torch.norm(viewspace_grad[update_filter, :2], dim=-1, keepdim=True)
     dn[update_filter] += 1
     return ga, dn
+
+
+def extend_from_pcd(state, xyz, features, scales, rots, opacities, kf_id):
+    """:210-236: a keyframe's new Gaussians appended through densification_postfix - `features` arrives as
+    [P, 3, K] (create_pcd_from_image, :199-205) and is split into f_dc [P, 1, 3] / f_rest [P, K - 1, 3]; the new rows
+    carry keyframe id `kf_id`, zero observation counts and zero Adam moments; the statistics restart for ALL rows."""
+    new = {"xyz": xyz, "f_dc": features[:, :, 0:1].transpose(1, 2).contiguous(),
+           "f_rest": features[:, :, 1:].transpose(1, 2).contiguous(), "opacity": opacities, "scaling": scales,
+           "rotation": rots, "kf": torch.ones(xyz.shape[0]).int() * kf_id, "n_obs": torch.zeros(xyz.shape[0]).int()}
+    return _append(state, new)

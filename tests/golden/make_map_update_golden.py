@@ -8,7 +8,8 @@ What is run (nothing of it is copied; only arrays - inputs and what the referenc
     steps to populate the moments, then densify_and_prune (:674-691; both max_screen_size cases, with and
     without f_rest) -> densify_and_clone (:636-672), densify_and_split (:598-634), densification_postfix /
     cat_tensors_to_optimizer (:525-596), prune_points / _prune_optimizer (:485-556); reset_opacity and
-    reset_opacity_nonvisible (:364-377, replace_tensor_to_optimizer :470-483); add_densification_stats (:693-697)
+    reset_opacity_nonvisible (:364-377, replace_tensor_to_optimizer :470-483); add_densification_stats (:693-697);
+    update_learning_rate (:298-312, general_utils.helper :80-95); extend_from_pcd (:210-236)
   * utils/slam_utils.py: ApplyExposure forward / backward in sketch mode (:115-185), two repeats over one
     forward, exposure_a positive AND negative (the backward is not the exact derivative: no sign(a), no eps)
 
@@ -167,6 +168,25 @@ for tag, n, rest, max_screen, seed in (("dp_screen", 900, 3, 20, 11), ("dp_plain
         out["ro_out_exp_avg"], out["ro_out_exp_avg_sq"] = s["exp_avg"].numpy().copy(), s["exp_avg_sq"].numpy().copy()
         # the other groups' moments are untouched by either reset
         out["ro_out_exp_avg_xyz"] = m.optimizer.state[m._xyz]["exp_avg"].numpy().copy()
+
+# ---- update_learning_rate (:298-312 -> general_utils.helper :80-95) and extend_from_pcd (:210-236) -----------
+m, g = make_model(400, 3, 21)
+its = np.array([0, 1, 10, 150, 1500, 15000, 29999, 30000, 45000], dtype=np.int64)
+out["lr_iterations"] = its
+out["lr_setup"] = np.array([Opt.position_lr_init, Opt.position_lr_final, Opt.position_lr_delay_mult,
+                            Opt.position_lr_max_steps, 6.0], dtype=np.float64)      # ..., spatial_lr_scale
+out["lr_values"] = np.array([m.update_learning_rate(int(i)) for i in its], dtype=np.float64)
+assert m.optimizer.param_groups[0]["lr"] == out["lr_values"][-1]
+put("ext_in", state(m))
+P, K = 57, 4                  # a keyframe's new points; features arrive as [P, 3, K] (create_pcd_from_image :199-205)
+new_xyz = torch.randn(P, 3, generator=g)
+new_feat = torch.randn(P, 3, K, generator=g)
+new_scales, new_rots, new_opac = torch.randn(P, 3, generator=g), torch.randn(P, 4, generator=g), torch.randn(P, 1, generator=g)
+out["ext_new_xyz"], out["ext_new_features"] = new_xyz.numpy().copy(), new_feat.numpy().copy()
+out["ext_new_scales"], out["ext_new_rots"], out["ext_new_opacities"] = new_scales.numpy().copy(), new_rots.numpy().copy(), new_opac.numpy().copy()
+out["ext_kf_id"] = np.array(13)
+m.extend_from_pcd(new_xyz, new_feat, new_scales, new_rots, new_opac, 13)
+put("ext_out", state(m))
 
 # ---- ApplyExposure in sketch mode (slam_utils.py:115-185) -------------------------------------------------
 g = torch.Generator().manual_seed(77)

@@ -104,3 +104,20 @@ def test_apply_exposure_matches_the_reference_in_sketch_mode(G, tag):
     if tag == "neg":      # not the exact derivative: d/da of (|a| + eps) image would carry sign(a) = -1
         exact = -(torch.from_numpy(G["ae_grad_out"][repeat - 1]) * im.detach()).sum()
         assert float(a.grad) * float(exact) < 0
+
+
+def test_learning_rate_schedule_matches_the_reference(G):
+    """GaussianModel.update_learning_rate (gaussian_model.py:298-312 -> general_utils.helper :80-95) at the iterations the
+    fixture holds, through the product's host-side mirror (monogs_amd.gaussian_model.expon_lr; pure Python, no GPU)."""
+    from monogs_amd.gaussian_model import expon_lr
+    init, final, delay_mult, max_steps, scale = (float(x) for x in G["lr_setup"])
+    for it, want in zip(G["lr_iterations"], G["lr_values"]):
+        got = expon_lr(int(it), init * scale, final * scale, lr_delay_mult=delay_mult, max_steps=int(max_steps))
+        assert abs(got - float(want)) <= 1e-12 * abs(float(want)), (int(it), got, float(want))
+    assert abs(float(G["lr_values"][0]) - init * scale) < 1e-15 and abs(float(G["lr_values"][-1]) - final * scale) < 1e-15
+
+
+def test_extend_from_pcd_restatement_matches_the_reference(G):
+    got = MR.extend_from_pcd(load_state(G, "ext_in"), *(torch.from_numpy(G[f"ext_new_{k}"]) for k in
+                             ("xyz", "features", "scales", "rots", "opacities")), int(G["ext_kf_id"]))
+    assert_state(got, load_state(G, "ext_out"), exact_keys=STATE_KEYS)
