@@ -12,6 +12,7 @@ What is run (nothing of it is copied; only arrays - inputs and what the referenc
     update_learning_rate (:298-312, general_utils.helper :80-95); extend_from_pcd (:210-236)
   * utils/slam_utils.py: ApplyExposure forward / backward in sketch mode (:115-185), two repeats over one
     forward, exposure_a positive AND negative (the backward is not the exact derivative: no sign(a), no eps)
+  * utils/pose_utils.py: the in-tree SE(3) exponential SE3_exp / SO3_exp / V (:13-74) in fp64 and fp32
 
 Import recipe = tests/test_cpu_reference_binding.py: utils.configs.cuda_device = "cpu" before anything else,
 EMPTY `open3d` / `plyfile` modules (not installed; nothing of either runs on these paths), `simple_knn` from
@@ -31,7 +32,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
 sys.path[:0] = [ROOT + "/dropin", ROOT, REF]
-for name in ("open3d", "plyfile"):
+for name in ("open3d", "plyfile", "lietorch"):
     sys.modules[name] = types.ModuleType(name)
 sys.modules["plyfile"].PlyData = sys.modules["plyfile"].PlyElement = object
 import utils.configs as _cfg  # noqa: E402
@@ -217,6 +218,22 @@ for tag, a0 in (("pos", 0.9), ("neg", -0.7)):
         out[f"ae_{tag}_r{r}_grad_image"] = im.grad.numpy().copy()
         out[f"ae_{tag}_r{r}_grad_a"], out[f"ae_{tag}_r{r}_grad_b"] = a.grad.numpy().copy(), b.grad.numpy().copy()
         out[f"ae_{tag}_r{r}_grad_sketch"] = sk.grad.numpy().copy()
+
+# ---- the in-tree SE(3) exponential (utils/pose_utils.py:13-74: skew_sym_mat, SO3_exp, V, SE3_exp) --------------------
+# pose_utils imports lietorch at its top (not installed: an EMPTY module stands in, as for open3d / plyfile); the four
+# functions run here are pure torch.  update_pose itself (:88-98) calls lietorch.SE3.exp and cannot run: it stays
+# pinned only through this closed form.
+import utils.pose_utils as PU  # noqa: E402
+g = torch.Generator().manual_seed(5)
+taus = torch.randn(12, 6, generator=g, dtype=torch.float64) * torch.tensor([0.3, 0.3, 0.3, 0.8, 0.8, 0.8], dtype=torch.float64)
+taus[0] = 0.0                                     # identity
+taus[1, 3:] = taus[1, 3:] * 1e-7                  # below the reference's small-angle threshold (1e-5)
+taus[2, 3:] = taus[2, 3:] / taus[2, 3:].norm() * 3.1      # close to pi
+out["pose_taus"] = taus.numpy()
+out["pose_SE3_exp_f64"] = torch.stack([PU.SE3_exp(t) for t in taus]).numpy()
+out["pose_SE3_exp_f32"] = torch.stack([PU.SE3_exp(t.float()) for t in taus]).numpy()
+out["pose_SO3_exp_f64"] = torch.stack([PU.SO3_exp(t[3:]) for t in taus]).numpy()
+out["pose_V_f64"] = torch.stack([PU.V(t[3:]) for t in taus]).numpy()
 
 path = os.path.join(HERE, "map_update_ref.npz")
 np.savez_compressed(path, **out)

@@ -121,3 +121,17 @@ def test_extend_from_pcd_restatement_matches_the_reference(G):
     got = MR.extend_from_pcd(load_state(G, "ext_in"), *(torch.from_numpy(G[f"ext_new_{k}"]) for k in
                              ("xyz", "features", "scales", "rots", "opacities")), int(G["ext_kf_id"]))
     assert_state(got, load_state(G, "ext_out"), exact_keys=STATE_KEYS)
+
+
+def test_se3_exponential_matches_the_reference(G):
+    """monogs_amd.pose.SE3_exp / SO3_exp / V (what update_pose applies, host side) against the reference's own in-tree
+    closed form (utils/pose_utils.py:13-74) incl. the identity, an angle below its small-angle threshold and one near
+    pi.  (The reference's update_pose calls lietorch.SE3.exp, pose_utils.py:92: lietorch is absent, so this closed form
+    - also checked against torch.linalg.matrix_exp in tests/test_cpu_oracle.py - is as far as the pin goes.)"""
+    from monogs_amd.pose import SE3_exp, SO3_exp, V
+    taus = torch.from_numpy(G["pose_taus"])
+    for i, t in enumerate(taus):
+        assert torch.allclose(SE3_exp(t), torch.from_numpy(G["pose_SE3_exp_f64"][i]), rtol=0, atol=1e-14), i
+        assert torch.allclose(SO3_exp(t[3:]), torch.from_numpy(G["pose_SO3_exp_f64"][i]), rtol=0, atol=1e-14), i
+        assert torch.allclose(V(t[3:]), torch.from_numpy(G["pose_V_f64"][i]), rtol=0, atol=1e-14), i
+        assert torch.allclose(SE3_exp(t.float()), torch.from_numpy(G["pose_SE3_exp_f32"][i]), rtol=0, atol=2e-6), i
