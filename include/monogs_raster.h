@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MGS_ABI_VERSION 7
+#define MGS_ABI_VERSION 8
 
 typedef enum mgs_status {
   MGS_OK = 0,

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MGS_LIB_PATH: load another build of the SAME library (kernel experiments, the -DMGS_STAMP build)
 LIB_PATH = os.environ.get("MGS_LIB_PATH") or os.path.join(_HERE, "lib", "libmonogs_raster.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 EXPORTS = (
     "mgs_abi_version", "mgs_struct_size", "mgs_status_string", "mgs_raster_workspace_query",
