@@ -13,9 +13,10 @@ What is run (nothing of it is copied; only arrays - inputs and what the referenc
   * utils/slam_utils.py: ApplyExposure forward / backward in sketch mode (:115-185), two repeats over one
     forward, exposure_a positive AND negative (the backward is not the exact derivative: no sign(a), no eps)
   * utils/pose_utils.py: the in-tree SE(3) exponential SE3_exp / SO3_exp / V (:13-74) in fp64 and fp32
+  * gaussian_splatting/utils/loss_utils.py: ssim (:61-101) and l1_loss (:21-22), what eval_rendering scores with
 
 Import recipe = tests/test_cpu_reference_binding.py: utils.configs.cuda_device = "cpu" before anything else,
-EMPTY `open3d` / `plyfile` modules (not installed; nothing of either runs on these paths), `simple_knn` from
+EMPTY `open3d` / `plyfile` / `lietorch` / `cv2` modules (not installed; nothing of any of them runs on these paths), `simple_knn` from
 dropin/.  `torch.cuda.synchronize` (called by ApplyExposure.backward for its timers, :134,181) is replaced by a
 no-op in THIS script.  The split's random draw (`torch.normal(mean=0, std=stds)`, :608-609) is recovered as unit
 normals by replaying the same generator state with std = 1 (asserted to reproduce the reference's samples bit
@@ -32,7 +33,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
 sys.path[:0] = [ROOT + "/dropin", ROOT, REF]
-for name in ("open3d", "plyfile", "lietorch"):
+for name in ("open3d", "plyfile", "lietorch", "cv2"):
     sys.modules[name] = types.ModuleType(name)
 sys.modules["plyfile"].PlyData = sys.modules["plyfile"].PlyElement = object
 import utils.configs as _cfg  # noqa: E402
@@ -234,6 +235,18 @@ out["pose_SE3_exp_f64"] = torch.stack([PU.SE3_exp(t) for t in taus]).numpy()
 out["pose_SE3_exp_f32"] = torch.stack([PU.SE3_exp(t.float()) for t in taus]).numpy()
 out["pose_SO3_exp_f64"] = torch.stack([PU.SO3_exp(t[3:]) for t in taus]).numpy()
 out["pose_V_f64"] = torch.stack([PU.V(t[3:]) for t in taus]).numpy()
+
+# ---- SSIM / L1 of the evaluation harness (gaussian_splatting/utils/loss_utils.py:21-22,61-101; eval_utils.py:147-150) -
+# loss_utils imports cv2 at its top for l1_loss_weight (not installed: an EMPTY module stands in); ssim / l1_loss are torch
+import gaussian_splatting.utils.loss_utils as LU  # noqa: E402
+g = torch.Generator().manual_seed(9)
+a = torch.rand(2, 3, 40, 52, generator=g)
+b = (a + 0.1 * torch.randn(2, 3, 40, 52, generator=g)).clamp(0, 1)
+out["ssim_a"], out["ssim_b"] = a.numpy(), b.numpy()
+out["ssim_mean"] = LU.ssim(a, b).numpy()
+out["ssim_per_image"] = LU.ssim(a, b, size_average=False).numpy()
+out["ssim_single"] = LU.ssim(a[:1], b[:1]).numpy()
+out["l1_loss"] = LU.l1_loss(a, b).numpy()
 
 path = os.path.join(HERE, "map_update_ref.npz")
 np.savez_compressed(path, **out)

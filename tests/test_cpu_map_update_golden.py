@@ -135,3 +135,15 @@ def test_se3_exponential_matches_the_reference(G):
         assert torch.allclose(SO3_exp(t[3:]), torch.from_numpy(G["pose_SO3_exp_f64"][i]), rtol=0, atol=1e-14), i
         assert torch.allclose(V(t[3:]), torch.from_numpy(G["pose_V_f64"][i]), rtol=0, atol=1e-14), i
         assert torch.allclose(SE3_exp(t.float()), torch.from_numpy(G["pose_SE3_exp_f32"][i]), rtol=0, atol=2e-6), i
+
+
+def test_ssim_matches_the_reference(G):
+    """eval_metrics.ssim (what the offline evaluation harness scores renders with, row f4) against the reference's own
+    gaussian_splatting/utils/loss_utils.py:61-101 (11x11 Gaussian window, sigma 1.5, zero padding, C1 / C2), mean and
+    per-image forms."""
+    from monogs_amd import eval_metrics as E
+    a, b = torch.from_numpy(G["ssim_a"]), torch.from_numpy(G["ssim_b"])
+    assert abs(float(E.ssim(a, b)) - float(G["ssim_mean"])) < 1e-6
+    assert torch.allclose(E.ssim(a, b, size_average=False), torch.from_numpy(G["ssim_per_image"]), atol=1e-6)
+    assert abs(float(E.ssim(a[:1], b[:1])) - float(G["ssim_single"])) < 1e-6
+    assert abs(float((a - b).abs().mean()) - float(G["l1_loss"])) < 1e-7
