@@ -15,6 +15,10 @@
 // Written as one asm block: the compiler otherwise SLP-packs neighbouring adds into
 // v_pk_add_f32 (no DPP modifier) and the DPP/permlane read-after-write wait states are
 // placed by hand (s_nop) because hipcc pads nothing inside an asm statement.
+// (The hazard itself - as hipcc's recogniser places it for the builtin forms - is two wait states between a VALU write
+// and a DPP / v_permlane*_swap read of the register, none behind a swap; the s_nop 1 behind every group below is more
+// than that.  Round 5 trimmed the ten-sum block to the minimum, five s_nop instead of ten, results identical: k_blend_bwd
+// 101.0 -> 103.0 us on one box, back to back, twice.  The padding stays: the idle slots go to the SIMD's other waves.)
 #pragma once
 #include <hip/hip_runtime.h>
 
