@@ -380,6 +380,13 @@ class GaussianRasterizer(nn.Module):
                 (scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception(
                 "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        if num_backward_gaussians is not None and int(num_backward_gaussians) >= 0:
+            # The fork's extension takes this keyword (gaussian_renderer/__init__.py:143,162; RGN.*.num_backward_gaussians,
+            # -1 in every shipped configuration, and slam_frontend.py:493-495 never forwards it).  What a non-negative
+            # value does lives in the absent CUDA source: refuse it loudly rather than ignore it silently.
+            raise NotImplementedError(
+                f"num_backward_gaussians={num_backward_gaussians}: only -1 (all Gaussians take part in the backward) is "
+                "implemented; the semantics of a limit are defined in the absent diff-gaussian-rasterization-w-pose source")
         dev = means3D.device
         if theta is None:
             theta = torch.zeros(3, dtype=torch.float32, device=dev)

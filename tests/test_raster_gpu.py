@@ -354,6 +354,11 @@ def test_argument_validation(built):
     with pytest.raises(RuntimeError):
         ras(means3D=m.cpu(), means2D=z.cpu(), opacities=o.cpu(), shs=sh.cpu(), scales=s.cpu(),
             rotations=r.cpu())
+    # the fork's num_backward_gaussians keyword: -1 (every shipped configuration) is accepted, a limit is refused
+    # loudly - its semantics live in the absent CUDA source
+    ras(means3D=m, means2D=z, opacities=o, shs=sh, scales=s, rotations=r, num_backward_gaussians=-1)
+    with pytest.raises(NotImplementedError):
+        ras(means3D=m, means2D=z, opacities=o, shs=sh, scales=s, rotations=r, num_backward_gaussians=300)
 
 
 def test_backward_with_a_pair_count_bound_below_the_true_count_is_flagged(built):
